@@ -1,0 +1,77 @@
+// common.h — shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libdcamd.
+// Wave = 64 lanes everywhere; no CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dcamd.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// 16 raw bytes, the unit of every global / LDS transfer in this library (a native vector so it
+// lives in 4 VGPRs; a struct-of-array form is demoted to scratch by hipcc).
+typedef __attribute__((ext_vector_type(4))) uint32_t chunk16;
+
+void dc_set_error(const char* fmt, ...);
+int dc_check_launch(const char* what);
+
+#define DC_REQUIRE(cond, code, ...) \
+  do { if (!(cond)) { dc_set_error(__VA_ARGS__); return (code); } } while (0)
+
+// ---- element traits ---------------------------------------------------------------
+template <typename T> struct Elem;
+
+template <> struct Elem<float> {
+  using vec = f32x4;
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<__bf16> {
+  using vec = bf16x8;
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+  static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }  // RNE, NaN-preserving
+};
+template <> struct Elem<_Float16> {
+  using vec = f16x8;
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ float to_f(_Float16 v) { return (float)v; }
+  static __device__ __forceinline__ _Float16 from_f(float v) { return (_Float16)v; }
+};
+
+template <typename T>
+__device__ __forceinline__ void chunk_to_f(const chunk16 c, float* f) {
+  const typename Elem<T>::vec v = __builtin_bit_cast(typename Elem<T>::vec, c);
+#pragma unroll
+  for (int i = 0; i < Elem<T>::EPC; ++i) f[i] = Elem<T>::to_f(v[i]);
+}
+template <typename T>
+__device__ __forceinline__ chunk16 f_to_chunk(const float* f) {
+  typename Elem<T>::vec v;
+#pragma unroll
+  for (int i = 0; i < Elem<T>::EPC; ++i) v[i] = Elem<T>::from_f(f[i]);
+  return __builtin_bit_cast(chunk16, v);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k = 0.79788456080286535588f;  // sqrt(2/pi)
+  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+
+// store one value of runtime dtype
+__device__ __forceinline__ void store_as(void* base, size_t idx, int dtype, float v) {
+  if (dtype == DC_F32) reinterpret_cast<float*>(base)[idx] = v;
+  else if (dtype == DC_BF16) reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+  else reinterpret_cast<_Float16*>(base)[idx] = (_Float16)v;
+}
+__device__ __forceinline__ float load_as(const void* base, size_t idx, int dtype) {
+  if (dtype == DC_F32) return reinterpret_cast<const float*>(base)[idx];
+  if (dtype == DC_BF16) return (float)reinterpret_cast<const __bf16*>(base)[idx];
+  return (float)reinterpret_cast<const _Float16*>(base)[idx];
+}
+
+static inline int dc_dtype_size(int dt) { return dt == DC_F32 ? 4 : 2; }

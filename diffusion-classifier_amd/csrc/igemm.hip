@@ -1,0 +1,330 @@
+// igemm.hip — implicit-GEMM convolution / GEMM on MFMA for gfx950.
+//
+// Replaces every Conv2d(3x3|1x1) and Linear of the diffusers backbone the reference calls
+// through nets/unet.py:186-195 and nets/dit.py:49-51 (cuDNN/cuBLAS there).
+//
+// Data layout: activations NHWC (rows = sample*H*W pixels, channels contiguous); weights
+// packed [Cout_pad][K], K contiguous, k = tap*(C0+C1) + c.  Both MFMA operands are therefore
+// K-contiguous and every global / LDS transfer is a 16-byte chunk.
+//
+// Tile: BM pixels x BN output channels per 256-thread workgroup (4 waves), K-step = 128 bytes
+// per row (64 bf16/f16 or 32 f32 elements), LDS double-buffered, register-staged prefetch of
+// the next K-step while the current one is on the matrix cores.  LDS rows are 128 B with the
+// 16-B chunk index XOR-swizzled by (row>>1)&7, which makes the ds_read_b128 fragment reads of
+// a 16-row MFMA operand conflict-free (MI355X LDS: 64 banks x 4 B, b128 served per 16 lanes).
+//
+// MFMA orientation: A-operand = weight rows (cout), B-operand = pixel rows, so the f32
+// accumulator of a lane is 4 CONSECUTIVE output channels of ONE pixel -> 8/16-byte NHWC stores.
+//   bf16/f16: v_mfma_f32_16x16x32_{bf16,f16};  f32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain).
+//
+// Block->tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) receive contiguous ranges of
+// the tile list, ordered M-fastest inside one N panel, so the workgroups sharing an L2 stream the
+// same weight panel.
+#include "common.h"
+
+struct IgemmArgs {
+  const void* src0; const int32_t* map0; const void* src1; const int32_t* map1;
+  const void* W; const float* bias;
+  const float* rowvec; const int32_t* rowvec_map;
+  const float* gate; const int32_t* gate_map;
+  const void* residual; const int32_t* res_map;
+  void* out;
+  int C0, C1, ld0, ld1, rowvec_ld, gate_ld, res_dtype, res_ld, out_dtype, out_ld, act;
+  int taps, stride, upsample, Hin, Win, Hout, Wout, Cout;
+  int M, Ktot, c0chunks, cpt, nk, tiles_m, tiles_n;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+  static __device__ __forceinline__ f32x4 run(const chunk16 w, const chunk16 x, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<_Float16> {
+  static __device__ __forceinline__ f32x4 run(const chunk16 w, const chunk16 x, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // Lane group q=lane>>4 holds k = 4q..4q+3 of a 16-wide k block; MFMA e consumes element e, so
+  // the four MFMAs cover all 16 k (a consistent k permutation on both operands).
+  static __device__ __forceinline__ f32x4 run(const chunk16 w, const chunk16 x, f32x4 acc) {
+    const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], xf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], xf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], xf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], xf[3], acc, 0, 0, 0);
+    return acc;
+  }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BKE = 8 * EPC;            // elements per K-step
+  constexpr int XL = BM / 32;             // 16-B X loads per thread per K-step
+  constexpr int WL = (BN + 31) / 32;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  static_assert(WGM * WGN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUF = (BM + BN) * 128;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  // ---- XCD-aware, bijective block -> tile map ----
+  int tile_m, tile_n;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile_n = lid / a.tiles_m;
+    tile_m = lid - tile_n * a.tiles_m;
+  }
+
+  const int HWo = a.Hout * a.Wout;
+  const int pad = (a.taps == 9) ? 1 : 0;
+  const int Hs = a.upsample ? (a.Hin >> 1) : a.Hin;
+  const int Ws = a.upsample ? (a.Win >> 1) : a.Win;
+  const int chunk = t & 7, lrow = t >> 3;
+
+  int ns0[XL], ns1[XL], iy0[XL], ix0[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int m = tile_m * BM + lrow + 32 * i;
+    const bool vm = m < a.M;
+    const int mm = vm ? m : 0;
+    const int n = mm / HWo;
+    const int rem = mm - n * HWo;
+    const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+    ns0[i] = a.map0 ? a.map0[n] : n;
+    ns1[i] = a.src1 ? (a.map1 ? a.map1[n] : n) : 0;
+    iy0[i] = vm ? oy * a.stride - pad : -(1 << 20);
+    ix0[i] = ox * a.stride - pad;
+  }
+  const T* wbase = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * BN + lrow) * a.Ktot + chunk * EPC;
+
+  chunk16 xr[XL], wr[WL];
+  const chunk16 zero = {0u, 0u, 0u, 0u};
+
+  auto load_regs = [&](int ks, int tap, int cc) {
+    int ky = 0, kx = 0;
+    if (a.taps == 9) { ky = tap / 3; kx = tap - ky * 3; }
+    const bool s1 = cc >= a.c0chunks;
+    const T* src = reinterpret_cast<const T*>(s1 ? a.src1 : a.src0);
+    const int ld = s1 ? a.ld1 : a.ld0;
+    const int coff = (s1 ? cc - a.c0chunks : cc) * BKE + chunk * EPC;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      const int sy = a.upsample ? (iy >> 1) : iy, sx = a.upsample ? (ix >> 1) : ix;
+      const size_t pix = ((size_t)(s1 ? ns1[i] : ns0[i]) * Hs + sy) * Ws + sx;
+      xr[i] = zero;
+      if (ok) xr[i] = *reinterpret_cast<const chunk16*>(src + pix * ld + coff);
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      if (BN >= 32 * (i + 1) || lrow + 32 * i < BN)
+        wr[i] = *reinterpret_cast<const chunk16*>(wbase + (size_t)(32 * i) * a.Ktot + (size_t)ks * BKE);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    char* Xs = smem + buf * BUF;
+    char* Wsm = Xs + BM * 128;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) *reinterpret_cast<chunk16*>(Xs + lds_off(lrow + 32 * i, chunk)) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WL; ++i)
+      if (BN >= 32 * (i + 1) || lrow + 32 * i < BN)
+        *reinterpret_cast<chunk16*>(Wsm + lds_off(lrow + 32 * i, chunk)) = wr[i];
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tap = 0, cc = 0;
+  load_regs(0, 0, 0);
+  write_lds(0);
+  __syncthreads();
+  for (int ks = 0; ks < a.nk; ++ks) {
+    const bool more = ks + 1 < a.nk;
+    if (more) {
+      if (++cc == a.cpt) { cc = 0; ++tap; }
+      load_regs(ks + 1, tap, cc);
+    }
+    const char* Xs = smem + (ks & 1) * BUF;
+    const char* Wsm = Xs + BM * 128;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int c = sub * 4 + lq;
+      chunk16 xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * WTM + j * 16 + lr, c));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wsm + lds_off(wn * WTN + i * 16 + lr, c));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    }
+    if (more) write_lds((ks + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds 4 consecutive couts (lq*4 + r) of pixel lr in every 16x16 tile ----
+  const bool geglu = a.act == DC_ACT_GEGLU;
+  const int cout_out = geglu ? (a.Cout >> 1) : a.Cout;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = tile_m * BM + wm * WTM + j * 16 + lr;
+    if (m >= a.M) continue;
+    const int n = m / HWo;
+    const float* rv = a.rowvec ? a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[n] : n) * a.rowvec_ld : nullptr;
+    const float* gt = a.gate ? a.gate + (size_t)(a.gate_map ? a.gate_map[n] : n) * a.gate_ld : nullptr;
+    size_t rrow = 0;
+    if (a.residual) rrow = (a.res_map ? (size_t)a.res_map[n] * HWo + (m - n * HWo) : (size_t)m) * a.res_ld;
+    const size_t orow = (size_t)m * a.out_ld;
+#pragma unroll
+    for (int i = 0; i < TN; i += 1) {
+      const int pc = tile_n * BN + wn * WTN + i * 16 + lq * 4;  // packed channel index
+      float v[4];
+      int oc;
+      if (geglu) {
+        if (i & 1) continue;
+        oc = ((tile_n * BN + wn * WTN + i * 16) >> 1) + lq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float val = acc[i][j][r], g = acc[(i + 1) % TN][j][r];
+          if (a.bias) { val += a.bias[pc + r]; g += a.bias[pc + 16 + r]; }
+          v[r] = val * gelu_erf_f(g);
+        }
+      } else {
+        oc = pc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[i][j][r];
+          const int c = oc + r;
+          if (c < cout_out) {
+            if (a.bias) x += a.bias[c];
+            if (rv) x += rv[c];
+            if (a.act == DC_ACT_SILU) x = silu_f(x);
+            else if (a.act == DC_ACT_GELU_TANH) x = gelu_tanh_f(x);
+            if (gt) x *= gt[c];
+          }
+          v[r] = x;
+        }
+      }
+      if (oc >= cout_out) continue;
+      if (a.residual) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (oc + r < cout_out) v[r] += load_as(a.residual, rrow + oc + r, a.res_dtype);
+      }
+      if (oc + 3 < cout_out && (a.out_ld & 3) == 0) {
+        if (a.out_dtype == DC_F32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow + oc) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (a.out_dtype == DC_BF16) {
+          __bf16 h[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + orow + oc) = *reinterpret_cast<uint2*>(h);
+        } else {
+          _Float16 h[4] = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+          *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(a.out) + orow + oc) = *reinterpret_cast<uint2*>(h);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (oc + r < cout_out) store_as(a.out, orow + oc + r, a.out_dtype, v[r]);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch(const IgemmArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_done = false;
+  auto kern = igemm_kernel<T, BM, BN, WGM, WGN>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  const long long nblk = (long long)a.tiles_m * a.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("dc_igemm: bad grid %lld", nblk); return DC_ERR_SHAPE; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, a);
+  return dc_check_launch("dc_igemm");
+}
+
+extern "C" int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n) {
+  const int tn = tile_n == 32 ? 32 : 128;
+  return (cout + tn - 1) / tn * tn;
+}
+
+extern "C" int dc_igemm(const dc_igemm_params* p, dc_stream stream) {
+  DC_REQUIRE(p, DC_ERR_ARG, "dc_igemm: null params");
+  DC_REQUIRE(p->dtype == DC_F32 || p->dtype == DC_BF16 || p->dtype == DC_F16, DC_ERR_DTYPE, "dc_igemm: dtype %d", p->dtype);
+  DC_REQUIRE(p->taps == 1 || p->taps == 9, DC_ERR_ARG, "dc_igemm: taps must be 1 or 9 (got %d)", p->taps);
+  DC_REQUIRE(p->stride == 1 || p->stride == 2, DC_ERR_ARG, "dc_igemm: stride %d", p->stride);
+  DC_REQUIRE(p->tile_n == 128 || p->tile_n == 32, DC_ERR_ARG, "dc_igemm: tile_n %d", p->tile_n);
+  DC_REQUIRE(p->src0 && p->W && p->out, DC_ERR_ARG, "dc_igemm: null src0/W/out");
+  const int bke = 128 / dc_dtype_size(p->dtype);
+  DC_REQUIRE(p->C0 > 0 && p->C0 % bke == 0, DC_ERR_SHAPE, "dc_igemm: C0=%d not a multiple of %d", p->C0, bke);
+  DC_REQUIRE(p->C1 >= 0 && p->C1 % bke == 0 && ((p->C1 > 0) == (p->src1 != nullptr)), DC_ERR_SHAPE,
+             "dc_igemm: C1=%d / src1 mismatch or not a multiple of %d", p->C1, bke);
+  DC_REQUIRE(p->n_img > 0 && p->Hout > 0 && p->Wout > 0 && p->Hin > 0 && p->Win > 0 && p->Cout > 0, DC_ERR_SHAPE,
+             "dc_igemm: non-positive extent");
+  if (p->taps == 9) {
+    DC_REQUIRE(p->Hout == (p->Hin + 2 - 3) / p->stride + 1 && p->Wout == (p->Win + 2 - 3) / p->stride + 1, DC_ERR_SHAPE,
+               "dc_igemm: 3x3 output %dx%d does not match input %dx%d stride %d", p->Hout, p->Wout, p->Hin, p->Win, p->stride);
+  } else {
+    DC_REQUIRE(p->stride == 1 && !p->upsample && p->Hout == p->Hin && p->Wout == p->Win, DC_ERR_SHAPE,
+               "dc_igemm: taps=1 needs stride 1, no upsample, equal in/out extents");
+  }
+  if (p->upsample) DC_REQUIRE((p->Hin % 2 == 0) && (p->Win % 2 == 0), DC_ERR_SHAPE, "dc_igemm: upsample needs even Hin/Win");
+  const long long M = (long long)p->n_img * p->Hout * p->Wout;
+  DC_REQUIRE(M < (1LL << 31), DC_ERR_SHAPE, "dc_igemm: M=%lld too large", M);
+  DC_REQUIRE(p->act >= 0 && p->act <= 3, DC_ERR_ARG, "dc_igemm: act %d", p->act);
+  if (p->act == DC_ACT_GEGLU) DC_REQUIRE(p->Cout % 32 == 0 && p->tile_n == 128, DC_ERR_SHAPE, "dc_igemm: GEGLU needs Cout%%32==0, tile_n 128");
+  DC_REQUIRE(((uintptr_t)p->src0 & 15) == 0 && ((uintptr_t)p->W & 15) == 0 && ((uintptr_t)p->src1 & 15) == 0, DC_ERR_ALIGN,
+             "dc_igemm: src/W must be 16-byte aligned");
+  const int epc = 16 / dc_dtype_size(p->dtype);
+  DC_REQUIRE(p->ld0 % epc == 0 && p->ld1 % epc == 0 && (p->ld0 == 0 || p->ld0 >= p->C0) && (p->ld1 == 0 || p->ld1 >= p->C1),
+             DC_ERR_SHAPE, "dc_igemm: ld0=%d ld1=%d", p->ld0, p->ld1);
+  const int cout_out = p->act == DC_ACT_GEGLU ? p->Cout / 2 : p->Cout;
+  DC_REQUIRE(p->out_ld >= cout_out, DC_ERR_SHAPE, "dc_igemm: out_ld %d < %d", p->out_ld, cout_out);
+  if (p->residual) DC_REQUIRE(p->res_ld >= cout_out, DC_ERR_SHAPE, "dc_igemm: res_ld");
+  if (p->rowvec) DC_REQUIRE(p->rowvec_ld >= cout_out, DC_ERR_SHAPE, "dc_igemm: rowvec_ld");
+  if (p->gate) DC_REQUIRE(p->gate_ld >= cout_out, DC_ERR_SHAPE, "dc_igemm: gate_ld");
+
+  IgemmArgs a;
+  a.src0 = p->src0; a.map0 = p->map0; a.src1 = p->src1; a.map1 = p->map1; a.W = p->W; a.bias = p->bias;
+  a.rowvec = p->rowvec; a.rowvec_map = p->rowvec_map; a.gate = p->gate; a.gate_map = p->gate_map;
+  a.residual = p->residual; a.res_map = p->res_map; a.out = p->out;
+  a.C0 = p->C0; a.C1 = p->C1; a.ld0 = p->ld0 ? p->ld0 : p->C0; a.ld1 = p->ld1 ? p->ld1 : p->C1;
+  a.rowvec_ld = p->rowvec_ld; a.gate_ld = p->gate_ld; a.res_dtype = p->res_dtype;
+  a.res_ld = p->res_ld; a.out_dtype = p->out_dtype; a.out_ld = p->out_ld; a.act = p->act;
+  a.taps = p->taps; a.stride = p->stride; a.upsample = p->upsample; a.Hin = p->Hin; a.Win = p->Win;
+  a.Hout = p->Hout; a.Wout = p->Wout; a.Cout = p->Cout;
+  a.M = (int)M; a.Ktot = p->taps * (p->C0 + p->C1);
+  a.c0chunks = p->C0 / bke; a.cpt = (p->C0 + p->C1) / bke; a.nk = p->taps * a.cpt;
+  const int bn = p->tile_n;
+  a.tiles_m = (a.M + 127) / 128;
+  a.tiles_n = dc_igemm_cout_pad(p->Cout, bn) / bn;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (bn == 128) {
+    if (p->dtype == DC_BF16) return launch<__bf16, 128, 128, 2, 2>(a, s);
+    if (p->dtype == DC_F16) return launch<_Float16, 128, 128, 2, 2>(a, s);
+    return launch<float, 128, 128, 2, 2>(a, s);
+  }
+  if (p->dtype == DC_BF16) return launch<__bf16, 128, 32, 4, 1>(a, s);
+  if (p->dtype == DC_F16) return launch<_Float16, 128, 32, 4, 1>(a, s);
+  return launch<float, 128, 32, 4, 1>(a, s);
+}

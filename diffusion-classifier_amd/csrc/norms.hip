@@ -1,0 +1,255 @@
+// norms.hip — GroupNorm(+SiLU) and LayerNorm(+adaLN modulate) for NHWC activations, gfx950.
+//
+// Replaces nn.GroupNorm / F.silu / nn.LayerNorm launches inside the diffusers backbone
+// (ResnetBlock2D norm1/norm2, Transformer2DModel.norm, conv_norm_out, BasicTransformerBlock
+// norm1/norm3, AdaLayerNormZero) reached through reference nets/unet.py:186 / nets/dit.py:49.
+// HBM-bound: every transfer is a 16-byte chunk per lane, statistics in fp32, deterministic
+// (fixed-order) reductions — no float atomics.
+#include "common.h"
+
+// ------------------------------------------------------------------ GroupNorm -----
+// Two launches. stats: grid (splits, n); each block reduces its pixel slice of one sample to
+// per-group (sum, sumsq) partials.  apply: same grid; each block folds the `splits` partials of
+// its sample in fixed order, then normalises (+affine, +SiLU) its pixel slice.
+// The input may be a channel-concat of two sources (skip connections are never materialised).
+struct GnArgs {
+  const void* x0; const int32_t* map0; const void* x1; const int32_t* map1;
+  void* y; const float* gamma; const float* beta; float* ws;
+  int C0, C1, HW, groups, silu, splits, out_dtype; float eps;
+};
+
+template <typename T>
+__device__ __forceinline__ const chunk16* gn_src(const GnArgs& a, int n, int col, int CP0, size_t pix_in_img, int& dummy) {
+  // chunk column `col` of the concatenated row -> pointer into the right source
+  if (col < CP0) {
+    const int ns = a.map0 ? a.map0[n] : n;
+    return reinterpret_cast<const chunk16*>(reinterpret_cast<const T*>(a.x0) + ((size_t)ns * a.HW + pix_in_img) * a.C0) + col;
+  }
+  const int ns = a.map1 ? a.map1[n] : n;
+  return reinterpret_cast<const chunk16*>(reinterpret_cast<const T*>(a.x1) + ((size_t)ns * a.HW + pix_in_img) * a.C1) + (col - CP0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][PL][Cround]
+  const int C = a.C0 + a.C1;
+  const int CP = C / EPC, CP0 = a.C0 / EPC;
+  int TPR = 1; while (TPR < CP && TPR < 256) TPR <<= 1;   // threads per pixel row (pow2 <= 256)
+  const int PL = 256 / TPR;                                // pixel lanes
+  const int npass = (CP + 255) / 256;                      // column passes when CP > 256
+  const int t = threadIdx.x, n = blockIdx.x / a.splits, s = blockIdx.x % a.splits;
+  const int p0 = (int)((long long)a.HW * s / a.splits), p1 = (int)((long long)a.HW * (s + 1) / a.splits);
+  const int tc = t % TPR, pl = t / TPR;
+  float* rs = red; float* rq = red + PL * C;
+  int dummy = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int col = pass * 256 + tc;
+    float sm[EPC], sq[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+    if (col < CP) {
+      for (int p = p0 + pl; p < p1; p += PL) {
+        const chunk16 c = *gn_src<T>(a, n, col, CP0, (size_t)p, dummy);
+        float f[EPC];
+        chunk_to_f<T>(c, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { rs[pl * C + col * EPC + e] = sm[e]; rq[pl * C + col * EPC + e] = sq[e]; }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / a.groups;
+  for (int g = t; g < a.groups; g += 256) {
+    float S = 0.f, Q = 0.f;
+    for (int l = 0; l < PL; ++l)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += rs[l * C + c]; Q += rq[l * C + c]; }
+    float* w = a.ws + (((size_t)n * a.splits + s) * a.groups + g) * 2;
+    w[0] = S; w[1] = Q;
+  }
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+  constexpr int EPC = Elem<T>::EPC;     // input chunk elements
+  extern __shared__ __attribute__((aligned(16))) float st[];  // mean[groups], rstd[groups]
+  const int C = a.C0 + a.C1;
+  const int CP = C / EPC, CP0 = a.C0 / EPC;
+  int TPR = 1; while (TPR < CP && TPR < 256) TPR <<= 1;
+  const int PL = 256 / TPR;
+  const int npass = (CP + 255) / 256;
+  const int t = threadIdx.x, n = blockIdx.x / a.splits, s = blockIdx.x % a.splits;
+  const int cpg = C / a.groups;
+  for (int g = t; g < a.groups; g += 256) {
+    float S = 0.f, Q = 0.f;
+    for (int k = 0; k < a.splits; ++k) {
+      const float* w = a.ws + (((size_t)n * a.splits + k) * a.groups + g) * 2;
+      S += w[0]; Q += w[1];
+    }
+    const float cnt = (float)cpg * (float)a.HW;
+    const float mean = S / cnt;
+    const float var = fmaxf(Q / cnt - mean * mean, 0.f);
+    st[g] = mean; st[a.groups + g] = rsqrtf(var + a.eps);
+  }
+  __syncthreads();
+  const int p0 = (int)((long long)a.HW * s / a.splits), p1 = (int)((long long)a.HW * (s + 1) / a.splits);
+  const int tc = t % TPR, pl = t / TPR;
+  int dummy = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int col = pass * 256 + tc;
+    if (col >= CP) continue;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int ch = col * EPC + e, g = ch / cpg;
+      const float r = st[a.groups + g] * a.gamma[ch];
+      sc[e] = r; sh[e] = a.beta[ch] - st[g] * r;
+    }
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const chunk16 c = *gn_src<T>(a, n, col, CP0, (size_t)p, dummy);
+      float f[EPC];
+      chunk_to_f<T>(c, f);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float v = f[e] * sc[e] + sh[e];
+        if (a.silu) v = silu_f(v);
+        f[e] = v;
+      }
+      TO* o = reinterpret_cast<TO*>(a.y) + ((size_t)n * a.HW + p) * C + (size_t)col * EPC;
+      if constexpr (sizeof(TO) * EPC == 16) {
+        *reinterpret_cast<chunk16*>(o) = f_to_chunk<TO>(f);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = Elem<TO>::from_f(f[e]);
+      }
+    }
+  }
+}
+
+extern "C" int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t splits) {
+  return (int64_t)n * groups * splits * 2;
+}
+extern "C" int32_t dc_groupnorm_splits(int32_t n, int32_t HW, int32_t C) {
+  // aim for >= ~2048 workgroups (256 CUs x 8) with >= 32 pixels each
+  int s = 1;
+  while ((long long)n * s < 2048 && HW / (s * 2) >= 32) s *= 2;
+  return s;
+}
+
+extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
+  DC_REQUIRE(p && p->x && p->y && p->gamma && p->beta && p->ws, DC_ERR_ARG, "dc_groupnorm: null pointer");
+  const int C1 = p->C1;
+  const int C = p->C + C1;
+  const int epc = 16 / dc_dtype_size(p->dtype);
+  DC_REQUIRE(p->groups > 0 && C % p->groups == 0, DC_ERR_SHAPE, "dc_groupnorm: C=%d groups=%d", C, p->groups);
+  DC_REQUIRE(p->C > 0 && p->C % epc == 0 && C1 >= 0 && C1 % epc == 0, DC_ERR_SHAPE,
+             "dc_groupnorm: C0=%d C1=%d must be multiples of %d", p->C, C1, epc);
+  DC_REQUIRE(p->n > 0 && p->HW > 0 && p->splits > 0 && p->splits <= p->HW, DC_ERR_SHAPE, "dc_groupnorm: n/HW/splits");
+  DC_REQUIRE((C1 > 0) == (p->x1 != nullptr), DC_ERR_ARG, "dc_groupnorm: x1/C1 mismatch");
+  DC_REQUIRE(p->dtype == p->out_dtype, DC_ERR_DTYPE, "dc_groupnorm: in/out dtype must match");
+  GnArgs a;
+  a.x0 = p->x; a.map0 = p->map0; a.x1 = p->x1; a.map1 = p->map1; a.y = p->y; a.gamma = p->gamma; a.beta = p->beta; a.ws = p->ws;
+  a.C0 = p->C; a.C1 = C1; a.HW = p->HW; a.groups = p->groups; a.silu = p->silu; a.splits = p->splits;
+  a.out_dtype = p->out_dtype; a.eps = p->eps;
+  const int CP = C / epc;
+  int TPR = 1; while (TPR < CP && TPR < 256) TPR <<= 1;
+  const int PL = 256 / TPR;
+  const size_t lds_stats = (size_t)2 * PL * C * sizeof(float);
+  DC_REQUIRE(lds_stats <= 64 * 1024, DC_ERR_SHAPE, "dc_groupnorm: C=%d too large", C);
+  const size_t lds_apply = (size_t)2 * p->groups * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long nb = (long long)p->splits * p->n;
+  DC_REQUIRE(nb < (1LL << 31), DC_ERR_SHAPE, "dc_groupnorm: grid too large");
+  dim3 grid((unsigned)nb), blk(256);
+  if (p->dtype == DC_F32) {
+    hipLaunchKernelGGL((gn_stats_kernel<float>), grid, blk, lds_stats, s, a);
+    hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, blk, lds_apply, s, a);
+  } else if (p->dtype == DC_BF16) {
+    hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, blk, lds_stats, s, a);
+    hipLaunchKernelGGL((gn_apply_kernel<__bf16, __bf16>), grid, blk, lds_apply, s, a);
+  } else if (p->dtype == DC_F16) {
+    hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, blk, lds_stats, s, a);
+    hipLaunchKernelGGL((gn_apply_kernel<_Float16, _Float16>), grid, blk, lds_apply, s, a);
+  } else {
+    dc_set_error("dc_groupnorm: dtype %d", p->dtype);
+    return DC_ERR_DTYPE;
+  }
+  return dc_check_launch("dc_groupnorm");
+}
+
+// ------------------------------------------------------------------ LayerNorm -----
+// One wave (64 lanes) per row; three sweeps over the row (mean, centred variance, normalise) —
+// the row (<= 8 KB) stays in L1/L2 after the first sweep, so HBM sees it once.
+struct LnArgs {
+  const void* x; void* y; const float* gamma; const float* beta; const float* scale; const float* shift;
+  const int32_t* mod_map; int rows, C, rows_per_sample, mod_ld; float eps;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_kernel(const LnArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int CP = a.C / EPC;
+  const chunk16* xr = reinterpret_cast<const chunk16*>(reinterpret_cast<const T*>(a.x) + (size_t)row * a.C);
+  float s = 0.f;
+  for (int c = lane; c < CP; c += 64) {
+    float f[EPC]; chunk_to_f<T>(xr[c], f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s += f[e];
+  }
+  const float mean = wave_sum(s) / (float)a.C;
+  float q = 0.f;
+  for (int c = lane; c < CP; c += 64) {
+    float f[EPC]; chunk_to_f<T>(xr[c], f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { const float d = f[e] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+  const float* sc = nullptr; const float* sh = nullptr;
+  if (a.scale) {
+    const int n = row / a.rows_per_sample;
+    const size_t o = (size_t)(a.mod_map ? a.mod_map[n] : n) * a.mod_ld;
+    sc = a.scale + o; sh = a.shift + o;
+  }
+  chunk16* yr = reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.y) + (size_t)row * a.C);
+  for (int c = lane; c < CP; c += 64) {
+    float f[EPC]; chunk_to_f<T>(xr[c], f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int ch = c * EPC + e;
+      float v = (f[e] - mean) * rstd;
+      if (a.gamma) v = v * a.gamma[ch] + a.beta[ch];
+      if (sc) v = v * (1.0f + sc[ch]) + sh[ch];
+      f[e] = v;
+    }
+    yr[c] = f_to_chunk<T>(f);
+  }
+}
+
+extern "C" int dc_layernorm(const dc_layernorm_params* p, dc_stream stream) {
+  DC_REQUIRE(p && p->x && p->y, DC_ERR_ARG, "dc_layernorm: null pointer");
+  DC_REQUIRE(p->dtype == p->out_dtype, DC_ERR_DTYPE, "dc_layernorm: in/out dtype must match");
+  const int epc = 16 / dc_dtype_size(p->dtype);
+  DC_REQUIRE(p->rows > 0 && p->C > 0 && p->C % epc == 0, DC_ERR_SHAPE, "dc_layernorm: rows=%d C=%d", p->rows, p->C);
+  DC_REQUIRE((p->gamma == nullptr) == (p->beta == nullptr), DC_ERR_ARG, "dc_layernorm: gamma/beta must both be set or null");
+  DC_REQUIRE((p->scale == nullptr) == (p->shift == nullptr), DC_ERR_ARG, "dc_layernorm: scale/shift must both be set or null");
+  if (p->scale) DC_REQUIRE(p->rows_per_sample > 0 && p->mod_ld >= p->C, DC_ERR_SHAPE, "dc_layernorm: rows_per_sample/mod_ld");
+  LnArgs a{p->x, p->y, p->gamma, p->beta, p->scale, p->shift, p->mod_map, p->rows, p->C, p->rows_per_sample, p->mod_ld, p->eps};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((p->rows + 3) / 4), blk(256);
+  if (p->dtype == DC_F32) hipLaunchKernelGGL((ln_kernel<float>), grid, blk, 0, s, a);
+  else if (p->dtype == DC_BF16) hipLaunchKernelGGL((ln_kernel<__bf16>), grid, blk, 0, s, a);
+  else if (p->dtype == DC_F16) hipLaunchKernelGGL((ln_kernel<_Float16>), grid, blk, 0, s, a);
+  else { dc_set_error("dc_layernorm: dtype %d", p->dtype); return DC_ERR_DTYPE; }
+  return dc_check_launch("dc_layernorm");
+}

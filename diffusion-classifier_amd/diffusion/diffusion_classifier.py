@@ -1,0 +1,353 @@
+"""MI355X-native drop-in for the scoring API of reference `diffusion/diffusion_classifier.py`.
+
+Kept surface (same names, argument meaning, assertions and return types):
+  DiffusionClassifier(backbone, config)                         reference :17-81
+  .classify(x, text=None, fast=False) -> LongTensor[BS]         reference :657-725
+  .evaluate(val_dataloader, stop_idx, metrics, classification)  reference :532-578
+  .encode_text_prompt / .diffuse / .logsnr_schedule_cosine(_shifted)  :83-161
+`config` is the reference's attribute bag (missing keys read as None).  Additive keys read
+here: `compute_dtype` ("bf16" default | "f16" | "f32"), `units_per_launch`, `shard_grid`.
+
+What differs is HOW classify runs.  The reference walks a Python double loop — T trials x C
+classes sequential eager backbone calls at batch BS (:686-714).  Here the (image, trial, class)
+grid is flattened into micro-batches of work units; each micro-batch is ONE native call
+(`dc_run_plan`) that enqueues q_sample -> backbone -> eps-MSE on the HIP stream, with z_t / eps
+materialised once per (image, trial), class-independent layers computed once per (image,
+trial), and errors scattered straight into `errors[b, class, j]`.  The stage end (mean over
+trials, top-k smallest, :718-721) runs on the gathered `errors` tensor with the same torch ops
+as the reference, identically on every rank.
+
+Extra keyword-only arguments (defaults keep the reference behaviour):
+  t, eps         inject the per-trial draws ([T,BS] and [T,BS,C,H,W]) — parity tests
+  fast_select    inject the `randint` draw of fast mode
+  return_errors  also return errors[BS, classes, T] (CPU)
+  rng            "reference": draw rand(BS) / randn_like(x) per trial in the reference's order;
+                 "philox":   t from the CPU generator, eps on device from Philox keyed by
+                             (seed, image, trial) — no eps traffic, world-size independent
+"""
+import math
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import dist as D
+from .._ema import EMA
+
+
+def log(t, eps=1e-20):
+    return torch.log(t.clamp(min=eps))
+
+
+class DiffusionClassifier(nn.Module):
+    def __init__(self, backbone: nn.Module, config):
+        super().__init__()
+        self.config = config
+        pred_param = self.config.pred_param
+        assert pred_param in ['v', 'eps'], "Invalid prediction parameterization. Must be 'v' or 'eps'"
+        self.pred_param = pred_param
+        schedule = self.config.schedule
+        assert schedule in ['cosine', 'shifted_cosine'], "Invalid schedule. Must be 'cosine' or 'shifted_cosine'"
+        self.schedule = self.logsnr_schedule_cosine if schedule == 'cosine' else self.logsnr_schedule_cosine_shifted
+        self.noise_d = self.config.noise_d
+        self.image_d = self.config.image_size
+        self.cfg_w = self.config.cfg_w
+        assert isinstance(backbone, nn.Module), "Model must be an instance of torch.nn.Module."
+        self.model = backbone
+        self.ema = EMA(self.model, beta=config.ema_beta, update_after_step=config.ema_warmup,
+                       update_every=config.ema_update_freq)
+        self.encoder_type = self.config.encoder_type
+        if self.encoder_type == 't5':
+            raise NotImplementedError("encoder_type='t5' fetches t5-base over the network; not part of the scoring path")
+        elif self.encoder_type == 'nn':
+            self.encoder = nn.Embedding(self.config.classes + 1, backbone.config.encoder_hid_dim)
+            self.tokenizer = None
+            self.null_token = self.config.classes
+        elif self.encoder_type == 'DiT':
+            self.tokenizer = None
+            self.encoder = None
+            self.null_token = self.config.classes
+        print(f"Parameter count: {sum(p.numel() for p in self.model.parameters())}")
+        self._score_plans = {}
+
+    # ---- small reference-identical helpers (host side, fp32 torch like the reference) -------
+    def encode_text_prompt(self, text):
+        if self.encoder_type == 'nn':
+            embeddings = self.encoder(text)
+            embeddings.unsqueeze_(1)
+        elif self.encoder_type == 'DiT':
+            embeddings = text
+        else:
+            raise NotImplementedError(self.encoder_type)
+        return embeddings
+
+    def diffuse(self, x, alpha_t, sigma_t):
+        eps_t = torch.randn_like(x)
+        return alpha_t * x + sigma_t * eps_t, eps_t
+
+    def logsnr_schedule_cosine(self, t, logsnr_min=-15, logsnr_max=15):
+        logsnr_max = logsnr_max + math.log(self.noise_d / self.image_d)
+        logsnr_min = logsnr_min + math.log(self.noise_d / self.image_d)
+        t_min = math.atan(math.exp(-0.5 * logsnr_max))
+        t_max = math.atan(math.exp(-0.5 * logsnr_min))
+        return -2 * log(torch.tan((t_min + t * (t_max - t_min)).clone().detach()))
+
+    def logsnr_schedule_cosine_shifted(self, t):
+        return self.logsnr_schedule_cosine(t) + 2 * math.log(self.noise_d / self.image_d)
+
+    # ---- the hot path ---------------------------------------------------------------------
+    @torch.no_grad()
+    def classify(self, x, text=None, fast=False, *, t=None, eps=None, fast_select=None, return_errors=False,
+                 rng="reference", seed=0):
+        cfg = self.config
+        assert self.encoder_type is not None, "Encoder must be provided for classification."
+        assert len(cfg.evaluation_per_stage) == cfg.n_stages, "Number of evaluations per stage must match the number of stages."
+        assert len(cfg.n_keep_per_stage) == cfg.n_stages, "Number of classes to keep per stage must match the number of stages."
+        assert cfg.n_keep_per_stage[-1] == 1, "Only one class should be selected at the end of the classification process."
+        assert cfg.n_fast_classes <= cfg.classes and cfg.n_fast_classes >= 2, "Number of fast classes must be less than or equal to the total number of classes. Must be at least 2."
+        assert rng in ("reference", "philox")
+        backbone = self.ema.ema_model
+        ends = [0] + list(cfg.evaluation_per_stage)
+        T, ncls = ends[-1], cfg.classes
+        BS = x.shape[0]
+        rank, ws = D.world() if cfg.shard_grid is not False else (0, 1)
+
+        # candidate classes per image (host, exactly the reference's ops :671-679)
+        if fast:
+            text_c = text.detach().cpu().view(-1, 1)
+            classes = torch.arange(ncls).repeat(BS, 1)
+            wrong = classes[(classes == text_c) == False].view(BS, -1)  # noqa: E712
+            sel = fast_select.cpu() if fast_select is not None else torch.randint(0, wrong.shape[1], (BS, cfg.n_fast_classes - 1))
+            classes = torch.cat((text_c, torch.gather(wrong, 1, sel)), dim=1)
+        else:
+            classes = torch.arange(ncls).repeat(BS, 1)
+
+        # per-trial draws.  reference order: t = rand(BS) then eps = randn_like(x), trial by trial (:688-692, :113)
+        eps_of = {}
+        if t is not None:
+            t_all = torch.as_tensor(t, dtype=torch.float32).cpu().reshape(T, BS)
+        elif rng == "reference":
+            t_rows = []
+            for j in range(T):
+                t_rows.append(torch.rand(BS))
+                if eps is None:
+                    eps_of[j] = torch.randn_like(x)
+            t_all = torch.stack(t_rows)
+        else:
+            t_all = torch.rand(T, BS)
+        if eps is not None:
+            eps_of = {j: eps[j] for j in range(T)}
+        elif rng == "reference" and not eps_of:
+            eps_of = {j: torch.randn_like(x) for j in range(T)}
+        # fp32 on the host, one [BS] vector per trial exactly like the reference (:689-691): torch's CPU
+        # kernels take different (vector / scalar-tail) code paths by element position, so evaluating the
+        # whole [T,BS] grid at once would differ from the reference in the last bit.
+        logsnr = torch.stack([self.schedule(t_all[j].clone()) for j in range(T)])
+        alpha_all = torch.stack([torch.sqrt(torch.sigmoid(logsnr[j].clone())) for j in range(T)])
+        sigma_all = torch.stack([torch.sqrt(torch.sigmoid(-logsnr[j].clone())) for j in range(T)])
+        draws = dict(logsnr=logsnr, alpha=alpha_all, sigma=sigma_all,
+                     eps_of=eps_of, philox=(rng == "philox" and eps is None), seed=int(seed))
+
+        if hasattr(backbone, "make_plan"):
+            runner = _HipRunner(self, backbone, x, T, draws)           # libdcamd; raises without GPU / library
+        else:
+            runner = _ForeignRunner(self, backbone, x, T, draws)       # user-supplied nn.Module, eager torch
+        for i in range(cfg.n_stages):
+            trials = D.local_trials(ends[i], ends[i + 1], rank, ws)
+            pairs = [(j, b) for j in trials for b in range(BS)]
+            runner.run_stage(pairs, classes)
+            errors = runner.errors()
+            D.gather_stage_errors(errors, ends[i], ends[i + 1], rank, ws)
+            errors_cpu = errors.cpu()
+            # stage end: identical torch ops to the reference (:718-721), on every rank
+            num_keep = cfg.n_keep_per_stage[i]
+            end_of_stage_errors = errors_cpu[:, :, :ends[i + 1]].mean(dim=2)
+            _, keep_indices = torch.topk(end_of_stage_errors, num_keep, dim=1, largest=False)
+            classes = keep_indices
+        assert classes.shape[1] == 1, "Only one class should be selected at the end of the classification process."
+        out = classes[:, 0].to(x.device)
+        return (out, errors_cpu) if return_errors else out
+
+    # ---- callers of the hot path (reference :532-578) ----------------------------------------
+    @torch.no_grad()
+    def evaluate(self, val_dataloader, stop_idx=None, metrics=None, classification=False, from_t=1):
+        val_samples, batches = [], []
+        for idx, batch in enumerate(val_dataloader):
+            batch = {k: v for k, v in batch.items()}
+            x = batch["images"]
+            p = batch["prompt"] if "prompt" in batch.keys() else None
+            if not classification:
+                raise NotImplementedError("sample() (DDPM generation, reference :210-293) is outside the scoring path")
+            sample = self.classify(x, p, fast=self.config.fast_classification)
+            if metrics is not None:
+                for metric in metrics:
+                    metric.update((sample, batch))
+            val_samples.append(sample)
+            batches.append(batch)
+            if stop_idx is not None and idx == stop_idx:
+                break
+        return val_samples, batches, metrics
+
+    def sample(self, x, text=None, from_t=1):
+        raise NotImplementedError("sample() (DDPM generation, reference :210-293) is outside the scoring path (SURVEY §8f row 4)")
+
+
+class _ForeignRunner:
+    """Backbones that are plain nn.Modules (not this package's HIP backbones): the reference's
+    semantics in eager torch on x.device, one backbone call per (trial, class column) at batch BS
+    (reference :686-714).  This is NOT a fallback for UNetCondition2D / DiT — those always take
+    _HipRunner and raise when libdcamd or the GPU is missing."""
+
+    def __init__(self, dc, backbone, x, T, draws):
+        if draws["philox"]:
+            raise L.DcamdError("rng='philox' needs a HIP backbone (UNetCondition2D / DiT)")
+        self.dc, self.bb, self.x, self.T, self.d = dc, backbone, x, T, draws
+        self.err = torch.full((x.shape[0], dc.config.classes, T), float("inf"), device=x.device)
+
+    def errors(self):
+        return self.err
+
+    def run_stage(self, pairs, classes):
+        dc, x, d = self.dc, self.x, self.d
+        by_trial = {}
+        for j, b in pairs:
+            by_trial.setdefault(j, []).append(b)
+        for j, bl in by_trial.items():
+            bs = torch.tensor(bl)
+            full = bl == list(range(x.shape[0]))       # the reference's own batch: use the tensors as they are
+            al = (d["alpha"][j] if full else d["alpha"][j, bs]).view(-1, 1, 1, 1).to(x.device)
+            sg = (d["sigma"][j] if full else d["sigma"][j, bs]).view(-1, 1, 1, 1).to(x.device)
+            lam = (d["logsnr"][j] if full else d["logsnr"][j, bs]).to(x.device)
+            e = d["eps_of"][j]
+            e = (e if full else e[bs.to(e.device)]).to(x.device)
+            z = al * (x if full else x[bs.to(x.device)]) + sg * e
+            for c in range(classes.shape[1]):
+                lab = classes[bs, c].to(x.device)
+                emb = dc.encode_text_prompt(lab)
+                pred = self.bb(x=z, noise_labels=lam, encoder_hidden_states=emb)
+                eps_pred = sg * z + al * pred if dc.pred_param == 'v' else pred
+                err = torch.norm((eps_pred - e).view(len(bl), -1), dim=1, p=2) ** 2
+                self.err[bs.to(x.device), lab, j] = err
+
+
+class _HipRunner:
+    """Micro-batched execution of the (image, trial, class) grid through libdcamd plans."""
+
+    def __init__(self, dc, backbone, x, T, draws):
+        self.lib = L.require_gpu()
+        self.dc, self.bb, self.x, self.T, self.d = dc, backbone, x, T, draws
+        self.dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        self.x_dev = x.detach().to(self.dev, torch.float32).contiguous()
+        self.err_dev = None
+        cfg = dc.config
+        dt = cfg.compute_dtype or "bf16"
+        if getattr(backbone, "compute_dtype", None) != dt:
+            backbone.set_compute_dtype(dt)
+        self.dt = dt
+        if draws["philox"]:
+            assert (x.shape[1] * x.shape[2] * x.shape[3]) % 4 == 0
+
+    def _units_per_launch(self, H, W, k):
+        u = self.dc.config.units_per_launch
+        if u is None:
+            u = max(1, (1 << 20) // (H * W))       # ~1M output pixel rows per launch at full resolution
+        return max(k, int(u))
+
+    def _plan(self, n_bj, k):
+        dc, dev = self.dc, self.dev
+        cfg = dc.config
+        BS, Cc, H, W = self.x.shape
+        key = (BS, n_bj, k, self.dt, str(dev), (Cc, H, W), bool(getattr(self.bb, "share_trunk", True)), id(self.bb))
+        sp = dc._score_plans.get(key)
+        if sp is not None:
+            return sp
+        U, T = n_bj * k, self.T
+        # one int32 control block: | pair_id (int64 x n_bj) | lam | alpha | sigma | img_of_bj | ctx_of_unit | out_index |
+        words = 2 * n_bj + 4 * n_bj + 2 * U
+        ctl = torch.zeros(words, dtype=torch.int32, device=dev)
+        o = [0]
+
+        def take(n):
+            v = ctl[o[0]:o[0] + n]
+            o[0] += n
+            return v
+        pair_id = take(2 * n_bj).view(torch.int64)
+        lam, alpha, sigma = (take(n_bj).view(torch.float32) for _ in range(3))
+        img_of_bj, ctx_of_unit, out_index = take(n_bj), take(U), take(U)
+        score = dict(
+            x=torch.zeros((BS, Cc, H, W), dtype=torch.float32, device=dev),
+            eps=torch.zeros((n_bj, Cc, H, W), dtype=torch.float32, device=dev),
+            errors=torch.full((BS * cfg.classes * T + 1,), float("inf"), dtype=torch.float32, device=dev),
+            lam=lam, alpha=alpha, sigma=sigma, img_of_bj=img_of_bj, ctx_of_unit=ctx_of_unit, out_index=out_index,
+            v_param=dc.pred_param == 'v')
+        plan = self.bb.make_plan(n_bj, k, cfg.classes, dev, score=score)
+        sp = dict(plan=plan, score=score, ctl=ctl, pair_id=pair_id, words=words, n_bj=n_bj, k=k, U=U)
+        dc._score_plans[key] = sp
+        return sp
+
+    def errors(self):
+        BS, ncls = self.x.shape[0], self.dc.config.classes
+        if self.err_dev is None:   # this rank owned no trial so far
+            self.err_dev = torch.full((BS * ncls * self.T + 1,), float("inf"), dtype=torch.float32, device=self.dev)
+        return self.err_dev[:-1].view(BS, ncls, self.T)
+
+    def run_stage(self, pairs, classes):
+        if not pairs:
+            return
+        dc, d, dev, T = self.dc, self.d, self.dev, self.T
+        BS, Cc, H, W = self.x.shape
+        ncls, k = dc.config.classes, classes.shape[1]
+        n_bj = min(len(pairs), max(1, self._units_per_launch(H, W, k) // k))
+        sp = self._plan(n_bj, k)
+        plan, score, U = sp["plan"], sp["score"], sp["U"]
+        if self.err_dev is None:
+            score["errors"].fill_(float("inf"))
+        elif score["errors"] is not self.err_dev:
+            score["errors"].copy_(self.err_dev)
+        self.err_dev = score["errors"]
+        score["x"].copy_(self.x_dev)
+        if dc.encoder is not None:
+            plan.ctx.copy_(dc.encoder.weight[:ncls].detach().to(dev, torch.float32))
+        n_mb = -(-len(pairs) // n_bj)
+        host = torch.zeros((n_mb, sp["words"]), dtype=torch.int32).pin_memory()
+        dump = BS * ncls * T
+        for m in range(n_mb):
+            chunk = pairs[m * n_bj:(m + 1) * n_bj]
+            row = host[m]
+            pad = n_bj - len(chunk)
+            js = torch.tensor([p[0] for p in chunk] + [chunk[0][0]] * pad)
+            bs = torch.tensor([p[1] for p in chunk] + [chunk[0][1]] * pad)
+            cl = classes[bs]                                           # [n_bj, k] class id of every unit
+            oi = (bs[:, None] * ncls + cl) * T + js[:, None]           # errors[b, class, j], flat
+            if pad:
+                oi[len(chunk):] = dump
+            o = 2 * n_bj
+            row[0:o].view(torch.int64).copy_(bs * T + js)
+            for src in (d["logsnr"], d["alpha"], d["sigma"]):
+                row[o:o + n_bj].view(torch.float32).copy_(src[js, bs])
+                o += n_bj
+            row[o:o + n_bj].copy_(bs.to(torch.int32)); o += n_bj
+            row[o:o + U].copy_(cl.reshape(-1).to(torch.int32)); o += U
+            row[o:o + U].copy_(oi.reshape(-1).to(torch.int32))
+        CHW = Cc * H * W
+        for m in range(n_mb):
+            chunk = pairs[m * n_bj:(m + 1) * n_bj]
+            sp["ctl"].copy_(host[m], non_blocking=True)
+            if d["philox"]:
+                L.check(self.lib.dc_philox_normal(score["eps"].data_ptr(), n_bj, CHW, sp["pair_id"].data_ptr(),
+                                                  d["seed"], L.stream_ptr()), "dc_philox_normal")
+            else:
+                r = 0
+                while r < len(chunk):                                  # runs of consecutive images of one trial
+                    j, b0 = chunk[r]
+                    r1 = r
+                    while r1 < len(chunk) and chunk[r1][0] == j and chunk[r1][1] == b0 + (r1 - r):
+                        r1 += 1
+                    score["eps"][r:r1].copy_(d["eps_of"][j][b0:b0 + (r1 - r)].to(torch.float32), non_blocking=True)
+                    r = r1
+                if len(chunk) < n_bj:
+                    score["eps"][len(chunk):].copy_(score["eps"][0:1].expand(n_bj - len(chunk), -1, -1, -1))
+            plan.run()
+        torch.cuda.current_stream().synchronize()    # `host` (pinned) must outlive the async copies

@@ -1,0 +1,569 @@
+"""Scoring-step engine: turns a backbone into a static launch plan for libdcamd.
+
+A *plan* is a flat array of `dc_op` records (include/dcamd.h) over one arena allocation.
+It is built once per (backbone, dtype, n_bj, n_cls) shape, then replayed with ONE native
+call (`dc_run_plan`) per micro-batch — the replacement for the reference's Python double
+loop body (diffusion/diffusion_classifier.py:695-714; ~600 eager launches per forward).
+
+Work unit = (image b, trial j, class c).  Tensors live in one of three *domains*:
+  'bj'   one sample per (image, trial) pair  — q_sample, time embedding, and every layer
+         before the first cross-attention (the class-shared trunk: computed once per pair,
+         never per class; exact, because class conditioning enters only through attn2);
+  'unit' one sample per (pair, class);
+  'ctx'  one row per class (class-token side path).
+When a 'unit' op reads a 'bj'/'ctx' tensor the kernel indexes it through an int32 map
+(bj_of_unit / ctx_of_unit), so nothing is ever broadcast-materialised and skip
+connections are never concatenated in memory.
+
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+DT = {"f32": L.DC_F32, "fp32": L.DC_F32, "float32": L.DC_F32, "bf16": L.DC_BF16, "bfloat16": L.DC_BF16,
+      "f16": L.DC_F16, "fp16": L.DC_F16, "float16": L.DC_F16}
+TORCH_DT = {L.DC_F32: torch.float32, L.DC_BF16: torch.bfloat16, L.DC_F16: torch.float16}
+DT_SIZE = {L.DC_F32: 4, L.DC_BF16: 2, L.DC_F16: 2}
+
+
+def bke(dt):
+    """K granule (elements per 128-byte LDS row) of dc_igemm for a dtype."""
+    return 128 // DT_SIZE[dt]
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class TRef:
+    """Handle of a plan tensor [n(dom), H, W, C] (NHWC) or a view of one."""
+    __slots__ = ("name", "dom", "H", "W", "C", "dt", "ld", "eoff", "base", "nbytes", "first", "last", "off", "ext")
+
+    def __init__(self, name, dom, H, W, C, dt, nbytes=0, ext=None):
+        self.name, self.dom, self.H, self.W, self.C, self.dt = name, dom, H, W, C, dt
+        self.ld, self.eoff, self.base = C, 0, self
+        self.nbytes, self.first, self.last, self.off, self.ext = nbytes, None, None, None, ext
+
+    def view(self, coff, C):
+        v = TRef(self.name + f"[{coff}:{coff + C}]", self.dom, self.H, self.W, C, self.dt)
+        v.ld, v.eoff, v.base = self.ld, self.eoff + coff, self.base
+        return v
+
+
+class PlanBuilder:
+    def __init__(self, device, n_bj, n_cls, n_ctx):
+        self.dev = device
+        self.n = {"bj": n_bj, "unit": n_bj * n_cls, "ctx": n_ctx}
+        self.ops = []        # (kind, struct_cls, fields{name: value | TRef | ("ptr", TRef)}, reads, writes)
+        self.keep = []       # torch tensors kept alive (weights, maps, inputs)
+        self.maps = {}       # (src_dom, dst_dom) -> external int32 TRef
+        self.arena = None
+        self.arena_bytes = 0
+        self._ws = None
+
+    # ---- tensors -------------------------------------------------------------------
+    def tensor(self, name, dom, H, W, Cc, dt):
+        nbytes = self.n[dom] * H * W * Cc * DT_SIZE[dt]
+        return TRef(name, dom, H, W, Cc, dt, nbytes=round_up(nbytes, 256))
+
+    def external(self, name, t, dom, H, W, Cc, dt):
+        assert t.is_contiguous() and t.device.type == "cuda", name
+        self.keep.append(t)
+        return TRef(name, dom, H, W, Cc, dt, ext=t)
+
+    def const(self, t):
+        """Device pointer of a constant (weight / bias / map) tensor kept alive by the plan."""
+        if t is None:
+            return None
+        assert t.is_contiguous() and t.device.type == "cuda"
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def set_map(self, src_dom, dst_dom, t):
+        self.maps[(src_dom, dst_dom)] = self.const(t)
+
+    def _map(self, src, dst_dom):
+        if src is None or src.dom == dst_dom:
+            return None
+        return self.maps[(src.dom, dst_dom)]
+
+    @staticmethod
+    def _dom(*ts):
+        doms = {t.dom for t in ts if t is not None}
+        if "unit" in doms or len(doms) > 1:   # bj x ctx -> one sample per (pair, class)
+            return "unit"
+        return doms.pop()
+
+    def _emit(self, kind, cls, fields, reads, writes):
+        idx = len(self.ops)
+        for t in reads + writes:
+            if t is None:
+                continue
+            b = t.base
+            if b.ext is None:
+                if b.first is None:
+                    b.first = idx
+                b.last = idx
+        self.ops.append((kind, cls, fields))
+
+    # ---- ops -----------------------------------------------------------------------
+    def igemm(self, name, src0, W, Cout, *, taps=1, stride=1, upsample=0, src1=None, bias=None, rowvec=None,
+              act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None):
+        dom = dom or self._dom(src0, src1, rowvec, gate, residual)
+        Hin, Win = (src0.H * 2, src0.W * 2) if upsample else (src0.H, src0.W)
+        if taps == 9:
+            Hout, Wout = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+        else:
+            Hout, Wout = Hin, Win
+        cout_out = Cout // 2 if act == L.ACT_GEGLU else Cout
+        out = self.tensor(name, dom, Hout, Wout, cout_out, src0.dt if out_dt is None else out_dt)
+        f = dict(dtype=src0.dt if wdt is None else wdt, taps=taps, stride=stride, upsample=upsample,
+                 n_img=self.n[dom], Hin=Hin, Win=Win, Hout=Hout, Wout=Wout,
+                 src0=src0, map0=self._map(src0, dom), C0=src0.C, ld0=src0.ld,
+                 src1=src1, map1=self._map(src1, dom), C1=src1.C if src1 is not None else 0,
+                 ld1=src1.ld if src1 is not None else 0,
+                 W=W, Cout=Cout, tile_n=tile_n, bias=bias,
+                 rowvec=rowvec, rowvec_map=self._map(rowvec, dom), rowvec_ld=rowvec.ld if rowvec is not None else 0,
+                 act=act, gate=gate, gate_map=self._map(gate, dom), gate_ld=gate.ld if gate is not None else 0,
+                 residual=residual, res_map=self._map(residual, dom),
+                 res_dtype=residual.dt if residual is not None else 0,
+                 res_ld=residual.ld if residual is not None else 0,
+                 out=out, out_dtype=out.dt, out_ld=out.ld)
+        if src1 is not None:
+            assert src1.dt == src0.dt and (src1.H, src1.W) == (src0.H, src0.W)
+        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual], [out])
+        return out
+
+    def groupnorm(self, name, x0, gamma, beta, groups, eps, silu, x1=None):
+        dom = self._dom(x0, x1)
+        Cc = x0.C + (x1.C if x1 is not None else 0)
+        assert x0.ld == x0.C and (x1 is None or x1.ld == x1.C)
+        out = self.tensor(name, dom, x0.H, x0.W, Cc, x0.dt)
+        n, HW = self.n[dom], x0.H * x0.W
+        splits = L.lib().dc_groupnorm_splits(n, HW, Cc)
+        ws_floats = L.lib().dc_groupnorm_ws_floats(n, groups, splits)
+        ws = TRef(name + ".ws", dom, 1, 1, 1, L.DC_F32, nbytes=round_up(ws_floats * 4, 256))
+        f = dict(x=x0, map0=self._map(x0, dom), x1=x1, map1=self._map(x1, dom), y=out, dtype=x0.dt, out_dtype=x0.dt,
+                 n=n, HW=HW, C=x0.C, C1=x1.C if x1 is not None else 0, groups=groups, silu=int(silu),
+                 splits=splits, eps=eps, gamma=gamma, beta=beta, ws=ws)
+        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1], [out, ws])
+        return out
+
+    def layernorm(self, name, x, gamma, beta, eps, scale=None, shift=None):
+        assert x.ld == x.C
+        assert scale is None or x.dom == "unit" or scale.dom == x.dom, "LayerNorm input must already be per-unit"
+        out = self.tensor(name, x.dom, x.H, x.W, x.C, x.dt)
+        f = dict(x=x, y=out, dtype=x.dt, out_dtype=x.dt, rows=self.n[x.dom] * x.H * x.W, C=x.C,
+                 rows_per_sample=x.H * x.W, mod_ld=scale.ld if scale is not None else 0, eps=eps,
+                 gamma=gamma, beta=beta, scale=scale, shift=shift, mod_map=self._map(scale, x.dom))
+        self._emit(L.OP_LAYERNORM, L.LayernormParams, f, [x, scale, shift], [out])
+        return out
+
+    def attention(self, name, q, k, v, heads):
+        out = self.tensor(name, q.dom, q.H, q.W, q.C, q.dt)
+        d = q.C // heads
+        f = dict(q=q, k=k, v=v, out=out, dtype=q.dt, n=self.n[q.dom], L=q.H * q.W, heads=heads, d=d,
+                 ld_qkv=q.ld, ld_out=out.ld, scale=float(d) ** -0.5)
+        self._emit(L.OP_ATTENTION, L.AttentionParams, f, [q, k, v], [out])
+        return out
+
+    def sinusoid(self, name, lam, dim, flip, shift):
+        out = self.tensor(name, lam.dom, 1, 1, dim, L.DC_F32)
+        f = dict(lam=lam, out=out, n=self.n[lam.dom], dim=dim, flip_sin_to_cos=int(flip), freq_shift=float(shift))
+        self._emit(L.OP_SINUSOID, L.SinusoidParams, f, [lam], [out])
+        return out
+
+    def qsample(self, name, x_ptr, eps, alpha, sigma, img_of_bj, Cin, H, W, ld, dt, im2col, patch=0):
+        g = patch if int(im2col) == 2 else 1
+        out = self.tensor(name, "bj", H // g, W // g, ld, dt)
+        f = dict(x=x_ptr, eps=eps, alpha=alpha, sigma=sigma, img_of_bj=img_of_bj, out=out, out_dtype=dt,
+                 n_bj=self.n["bj"], C=Cin, H=H, W=W, ld=ld, im2col=int(im2col), patch=int(patch))
+        self._emit(L.OP_QSAMPLE, L.QsampleParams, f, [eps, alpha, sigma], [out])
+        return out
+
+    def eps_mse(self, pred, eps, x_ptr, alpha, sigma, bj_of_unit, img_of_bj, out_index, out_ptr, Cin, v_param, patch=0):
+        g = patch if patch > 1 else 1
+        f = dict(pred=pred, eps=eps, x=x_ptr, alpha=alpha, sigma=sigma, bj_of_unit=bj_of_unit, img_of_bj=img_of_bj,
+                 out_index=out_index, out=out_ptr, n_units=self.n["unit"], C=Cin, H=pred.H * g, W=pred.W * g, ld=pred.ld,
+                 v_param=int(v_param), patch=int(patch))
+        self._emit(L.OP_EPS_MSE, L.EpsMseParams, f, [pred, eps, alpha, sigma], [])
+
+    # ---- finalize: liveness-based arena + ctypes records ----------------------------
+    def finalize(self, keep_alive=()):
+        """keep_alive: tensors that must survive to the end of the plan (outputs)."""
+        nops = len(self.ops)
+        for t in keep_alive:
+            t.base.last = nops
+        bases = {}
+        for _, _, f in self.ops:
+            for v in f.values():
+                if isinstance(v, TRef) and v.base.ext is None:
+                    bases[id(v.base)] = v.base
+        order = sorted(bases.values(), key=lambda b: b.first)
+        by_last = {}
+        for b in order:
+            by_last.setdefault(b.last, []).append(b)
+        free, top = [], 0   # free: list of (off, size)
+        pending = iter(order)
+        nxt = next(pending, None)
+        for idx in range(nops + 1):
+            while nxt is not None and nxt.first == idx:
+                need = nxt.nbytes
+                best = None
+                for i, (o, s) in enumerate(free):
+                    if s >= need and (best is None or s < free[best][1]):
+                        best = i
+                if best is not None:
+                    o, s = free.pop(best)
+                    nxt.off = o
+                    if s > need:
+                        free.append((o + need, s - need))
+                else:
+                    nxt.off = top
+                    top += need
+                nxt = next(pending, None)
+            for b in by_last.get(idx, []):
+                free.append((b.off, b.nbytes))
+                free.sort()
+                merged = []
+                for o, s in free:
+                    if merged and merged[-1][0] + merged[-1][1] == o:
+                        merged[-1] = (merged[-1][0], merged[-1][1] + s)
+                    else:
+                        merged.append((o, s))
+                free = merged
+        self.arena_bytes = top
+        self.arena = torch.empty(max(top, 256), dtype=torch.uint8, device=self.dev)
+        base_ptr = self.arena.data_ptr()
+        assert base_ptr % 256 == 0
+
+        def ptr(v):
+            if v is None:
+                return None
+            if isinstance(v, TRef):
+                b = v.base
+                p0 = b.ext.data_ptr() if b.ext is not None else base_ptr + b.off
+                return p0 + v.eoff * DT_SIZE[v.dt]
+            return v
+
+        self.structs = []
+        arr = (L.Op * nops)()
+        for i, (kind, cls, f) in enumerate(self.ops):
+            s = cls()
+            for name, ctype in cls._fields_:
+                if name not in f:
+                    continue
+                v = f[name]
+                if ctype is L.vp:
+                    setattr(s, name, ptr(v))
+                else:
+                    setattr(s, name, v)
+            self.structs.append(s)
+            arr[i].kind = kind
+            arr[i].params = C.cast(C.pointer(s), C.c_void_p)
+        self.op_array = arr
+        self.nops = nops
+        self.ptr_of = ptr
+        return self
+
+    def run(self):
+        L.check(L.lib().dc_run_plan(self.op_array, self.nops, L.stream_ptr()), "dc_run_plan")
+
+    def tensor_view(self, t):
+        """torch view of an arena/external tensor (tests and the plain forward read results through it)."""
+        n = self.n[t.dom]
+        assert t.ld == t.C and t.eoff == 0
+        if t.base.ext is not None:
+            return t.base.ext
+        nel = n * t.H * t.W * t.C
+        off = t.base.off
+        return self.arena[off:off + nel * DT_SIZE[t.dt]].view(TORCH_DT[t.dt]).view(n, t.H, t.W, t.C)
+
+
+# ======================================================================================
+#                                   weight packing
+# ======================================================================================
+def _pad_rows(w, rows):
+    if w.shape[0] == rows:
+        return w
+    out = torch.zeros((rows,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    out[: w.shape[0]] = w
+    return out
+
+
+def pack_matrix(w2d, dt, device, tile_n=128):
+    """[Cout, K] fp32 -> packed [Cout_pad, K] in dt (rows zero padded to the N tile)."""
+    rows = L.lib().dc_igemm_cout_pad(w2d.shape[0], tile_n)
+    return _pad_rows(w2d.detach().to(device=device, dtype=torch.float32), rows).to(TORCH_DT[dt]).contiguous()
+
+
+def pack_conv3x3(w, dt, device, tile_n=128, kpad=None):
+    """[Cout, Cin, 3, 3] -> [Cout_pad, 9*Cin (padded to kpad)], k = (ky*3+kx)*Cin + c."""
+    co, ci = w.shape[0], w.shape[1]
+    m = w.detach().permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    if kpad is not None and kpad != 9 * ci:
+        mm = torch.zeros(co, kpad, dtype=m.dtype, device=m.device)
+        mm[:, : 9 * ci] = m
+        m = mm
+    return pack_matrix(m, dt, device, tile_n)
+
+
+def geglu_perm(n_half):
+    """Row order of the packed GEGLU projection: 16-row blocks alternate value / gate halves."""
+    assert n_half % 16 == 0
+    idx = []
+    for b in range(n_half // 16):
+        idx += list(range(16 * b, 16 * b + 16))
+        idx += list(range(n_half + 16 * b, n_half + 16 * b + 16))
+    return torch.tensor(idx, dtype=torch.long)
+
+
+def f32c(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def pad_vec(v, rows):
+    if v.shape[0] == rows:
+        return v
+    out = torch.zeros(rows, dtype=v.dtype, device=v.device)
+    out[: v.shape[0]] = v
+    return out
+
+
+class UNetWeights:
+    """Device-resident packed weights of a UNetCondition2D for one compute dtype."""
+
+    def __init__(self, model, dt, device):
+        self.dt, self.dev = dt, device
+        cfg = model.config
+        self.kin = round_up(9 * cfg.in_channels, bke(dt))
+        P = {}
+        sd = {k: v for k, v in model.state_dict().items()}
+
+        def conv3(key, tile_n=128, kpad=None):
+            P[key + ".w"] = pack_conv3x3(sd[key + ".weight"], dt, device, tile_n, kpad)
+            P[key + ".b"] = f32c(sd[key + ".bias"], device)
+
+        def conv1(key):
+            w = sd[key + ".weight"]
+            P[key + ".w"] = pack_matrix(w.reshape(w.shape[0], -1), dt, device)
+            P[key + ".b"] = f32c(sd[key + ".bias"], device)
+
+        def lin(key, dtype=None, bias=True):
+            P[key + ".w"] = pack_matrix(sd[key + ".weight"], dt if dtype is None else dtype, device)
+            if bias and key + ".bias" in sd:
+                P[key + ".b"] = f32c(sd[key + ".bias"], device)
+
+        def norm(key):
+            P[key + ".g"] = f32c(sd[key + ".weight"], device)
+            P[key + ".b"] = f32c(sd[key + ".bias"], device)
+
+        conv3("conv_in", kpad=self.kin)
+        lin("time_embedding.linear_1", L.DC_F32)
+        lin("time_embedding.linear_2", L.DC_F32)
+        lin("encoder_hid_proj", L.DC_F32)
+        norm("conv_norm_out")
+        conv3("conv_out", tile_n=32 if cfg.out_channels <= 32 else 128)
+        self.resnets, self.attns = [], []
+        for k in sd:
+            if k.endswith("samplers.0.conv.weight"):
+                conv3(k[: -len(".weight")])
+        for key in sorted({k.rsplit(".", 2)[0] for k in sd if k.endswith(".time_emb_proj.weight")}):
+            self.resnets.append(key)
+            norm(key + ".norm1"); conv3(key + ".conv1"); norm(key + ".norm2"); conv3(key + ".conv2")
+            if key + ".conv_shortcut.weight" in sd:
+                conv1(key + ".conv_shortcut")
+        # all time_emb_proj stacked into one [sum Cout, 4*C0] fp32 GEMM
+        tw = torch.cat([sd[k + ".time_emb_proj.weight"] for k in self.resnets], 0)
+        tb = torch.cat([sd[k + ".time_emb_proj.bias"] for k in self.resnets], 0)
+        self.tproj_off, o = {}, 0
+        for k in self.resnets:
+            self.tproj_off[k] = o
+            o += sd[k + ".time_emb_proj.weight"].shape[0]
+        self.tproj_total = o
+        P["tproj.w"] = pack_matrix(tw, L.DC_F32, device)
+        P["tproj.b"] = f32c(tb, device)
+        for key in sorted({k[: -len(".proj_in.weight")] for k in sd if k.endswith(".proj_in.weight")}):
+            self.attns.append(key)
+            norm(key + ".norm"); conv1(key + ".proj_in"); conv1(key + ".proj_out")
+            tb_ = key + ".transformer_blocks.0"
+            norm(tb_ + ".norm1"); norm(tb_ + ".norm3")
+            qkv = torch.cat([sd[tb_ + f".attn1.to_{n}.weight"] for n in "qkv"], 0)
+            P[tb_ + ".qkv.w"] = pack_matrix(qkv, dt, device)
+            lin(tb_ + ".attn1.to_out.0")
+            pw, pb = sd[tb_ + ".ff.net.0.proj.weight"], sd[tb_ + ".ff.net.0.proj.bias"]
+            perm = geglu_perm(pw.shape[0] // 2)
+            P[tb_ + ".ff.net.0.proj.w"] = pack_matrix(pw[perm], dt, device)
+            P[tb_ + ".ff.net.0.proj.b"] = f32c(pb[perm], device)
+            lin(tb_ + ".ff.net.2")
+            # class-token side path (fp32): to_v then to_out of attn2 (to_q/to_k never matter for 1 key)
+            lin(tb_ + ".attn2.to_out.0", L.DC_F32)
+        vw = torch.cat([sd[k + ".transformer_blocks.0.attn2.to_v.weight"] for k in self.attns], 0)
+        self.cv_off, o = {}, 0
+        for k in self.attns:
+            self.cv_off[k] = o
+            o += sd[k + ".transformer_blocks.0.attn2.to_v.weight"].shape[0]
+        self.cv_total = o
+        P["attn2v.w"] = pack_matrix(vw, L.DC_F32, device)
+        self.P = P
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.P.values())
+
+
+# ======================================================================================
+#                                   UNet plan
+# ======================================================================================
+class UNetPlan:
+    """Static launch plan of one UNetCondition2D scoring step.
+
+    inputs (plan-owned device buffers, refreshed per micro-batch by the caller):
+      lam [n_bj] f32;  ctx [n_ctx, hid] f32;  a0 = conv_in GEMM operand [n_bj, H, W, kin]
+      (written by the q_sample op when `score=True`, else by the caller through `a0_view`);
+      maps bj_of_unit / ctx_of_unit [U] int32.
+    output: pred [U, H, W, out_channels] f32 (NHWC); with score=True also err -> errors buffer.
+    """
+
+    def __init__(self, model, weights, n_bj, n_cls, n_ctx, *, share_trunk=True, score=None, device=None):
+        cfg = model.config
+        dev = device or weights.dev
+        dt = weights.dt
+        self.dt, self.n_bj, self.n_cls, self.n_ctx = dt, n_bj, n_cls, n_ctx
+        U = n_bj * n_cls
+        pb = PlanBuilder(dev, n_bj, n_cls, n_ctx)
+        self.pb = pb
+        P = weights.P
+        H = W = cfg.sample_size
+        C0 = cfg.block_out_channels[0]
+        G, eps = cfg.norm_num_groups, cfg.norm_eps
+        heads = cfg.attention_head_dim
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        # ---- inputs ----
+        self.lam = score["lam"] if score is not None and "lam" in score else torch.zeros(n_bj, **f32)
+        self.ctx = torch.zeros(n_ctx, cfg.encoder_hid_dim, **f32)
+        self.bj_of_unit = (torch.arange(U, **i32) // n_cls).contiguous()
+        if score is not None and "ctx_of_unit" in score:
+            self.ctx_of_unit = score["ctx_of_unit"]
+        else:
+            self.ctx_of_unit = (torch.arange(U, **i32) % n_ctx).contiguous()
+        pb.set_map("bj", "unit", self.bj_of_unit)
+        pb.set_map("ctx", "unit", self.ctx_of_unit)
+        lam = pb.external("lam", self.lam, "bj", 1, 1, 1, L.DC_F32)
+        ctx = pb.external("ctx", self.ctx, "ctx", 1, 1, cfg.encoder_hid_dim, L.DC_F32)
+        kin = weights.kin
+        if score is not None:
+            # score = dict(x=[B,C,H,W] f32 buffer, eps=[n_bj,C,H,W], alpha, sigma, img_of_bj, out_index, errors, v_param)
+            self.score = score
+            eps_t = pb.external("eps", score["eps"], "bj", 1, 1, 1, L.DC_F32)
+            al = pb.external("alpha", score["alpha"], "bj", 1, 1, 1, L.DC_F32)
+            sg = pb.external("sigma", score["sigma"], "bj", 1, 1, 1, L.DC_F32)
+            a0 = pb.qsample("a0", pb.const(score["x"]), eps_t, al, sg, pb.const(score["img_of_bj"]),
+                            cfg.in_channels, H, W, kin, dt, im2col=True)
+        else:
+            self.a0_buf = torch.zeros(n_bj, H, W, kin, dtype=TORCH_DT[dt], device=dev)
+            a0 = pb.external("a0", self.a0_buf, "bj", H, W, kin, dt)
+        # ---- fp32 side path: time embedding, stacked time_emb_proj, class-token vectors ----
+        te = pb.sinusoid("temb.sin", lam, C0, cfg.flip_sin_to_cos, cfg.freq_shift)
+        te = pb.igemm("temb.l1", te, pb.const(P["time_embedding.linear_1.w"]), 4 * C0,
+                      bias=pb.const(P["time_embedding.linear_1.b"]), act=L.ACT_SILU)
+        te = pb.igemm("temb.l2", te, pb.const(P["time_embedding.linear_2.w"]), 4 * C0,
+                      bias=pb.const(P["time_embedding.linear_2.b"]), act=L.ACT_SILU)   # = SiLU(temb)
+        tproj = pb.igemm("tproj", te, pb.const(P["tproj.w"]), weights.tproj_total, bias=pb.const(P["tproj.b"]))
+        hp = pb.igemm("ctx.hid_proj", ctx, pb.const(P["encoder_hid_proj.w"]), cfg.cross_attention_dim,
+                      bias=pb.const(P["encoder_hid_proj.b"]))
+        vall = pb.igemm("ctx.to_v", hp, pb.const(P["attn2v.w"]), weights.cv_total)
+        cvec = {}
+        for k in weights.attns:
+            tbk = k + ".transformer_blocks.0"
+            Ck = P[k + ".norm.g"].shape[0]
+            cvec[k] = pb.igemm(k + ".cvec", vall.view(weights.cv_off[k], Ck), pb.const(P[tbk + ".attn2.to_out.0.w"]), Ck,
+                               bias=pb.const(P[tbk + ".attn2.to_out.0.b"]))
+
+        def resnet(key, x0, x1=None):
+            Cout = P[key + ".conv1.b"].shape[0]
+            h = pb.groupnorm(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, True, x1=x1)
+            h = pb.igemm(key + ".conv1", h, pb.const(P[key + ".conv1.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
+                         rowvec=tproj.view(weights.tproj_off[key], Cout))
+            h = pb.groupnorm(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps, True)
+            if key + ".conv_shortcut.w" in P:
+                sc = pb.igemm(key + ".short", x0, pb.const(P[key + ".conv_shortcut.w"]), Cout, src1=x1,
+                              bias=pb.const(P[key + ".conv_shortcut.b"]))
+            else:
+                assert x1 is None
+                sc = x0
+            return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.b"]),
+                            residual=sc)
+
+        def transformer(key, x):
+            Cc = x.C
+            tbk = key + ".transformer_blocks.0"
+            h = pb.groupnorm(key + ".gn", x, pb.const(P[key + ".norm.g"]), pb.const(P[key + ".norm.b"]), G, 1e-6, False)
+            h = pb.igemm(key + ".proj_in", h, pb.const(P[key + ".proj_in.w"]), Cc, bias=pb.const(P[key + ".proj_in.b"]))
+            hn = pb.layernorm(tbk + ".ln1", h, pb.const(P[tbk + ".norm1.g"]), pb.const(P[tbk + ".norm1.b"]), 1e-5)
+            qkv = pb.igemm(tbk + ".qkv", hn, pb.const(P[tbk + ".qkv.w"]), 3 * Cc)
+            o = pb.attention(tbk + ".attn1", qkv.view(0, Cc), qkv.view(Cc, Cc), qkv.view(2 * Cc, Cc), heads)
+            h = pb.igemm(tbk + ".attn_out", o, pb.const(P[tbk + ".attn1.to_out.0.w"]), Cc,
+                         bias=pb.const(P[tbk + ".attn1.to_out.0.b"]), rowvec=cvec[key], residual=h)
+            hn = pb.layernorm(tbk + ".ln3", h, pb.const(P[tbk + ".norm3.g"]), pb.const(P[tbk + ".norm3.b"]), 1e-5)
+            f = pb.igemm(tbk + ".geglu", hn, pb.const(P[tbk + ".ff.net.0.proj.w"]), 8 * Cc,
+                         bias=pb.const(P[tbk + ".ff.net.0.proj.b"]), act=L.ACT_GEGLU)
+            h = pb.igemm(tbk + ".ff_out", f, pb.const(P[tbk + ".ff.net.2.w"]), Cc, bias=pb.const(P[tbk + ".ff.net.2.b"]),
+                         residual=h)
+            return pb.igemm(key + ".proj_out", h, pb.const(P[key + ".proj_out.w"]), Cc, bias=pb.const(P[key + ".proj_out.b"]),
+                            residual=x)
+
+        # ---- main path ----
+        # share_trunk=False recomputes the class-independent layers per unit (reference-equivalent
+        # executed FLOPs; used for A/B tests): conv_in then reads its operand through bj_of_unit.
+        h = pb.igemm("conv_in", a0, pb.const(P["conv_in.w"]), C0, bias=pb.const(P["conv_in.b"]),
+                     dom=None if share_trunk else "unit")
+        skips = [h]
+        boc = cfg.block_out_channels
+        for i, kind in enumerate(cfg.down_block_types):
+            for j in range(cfg.layers_per_block[i]):
+                h = resnet(f"down_blocks.{i}.resnets.{j}", h)
+                if kind == "CrossAttnDownBlock2D":
+                    h = transformer(f"down_blocks.{i}.attentions.{j}", h)
+                skips.append(h)
+            if i != len(boc) - 1:
+                key = f"down_blocks.{i}.downsamplers.0.conv"
+                h = pb.igemm(key, h, pb.const(P[key + ".w"]), boc[i], taps=9, stride=2, bias=pb.const(P[key + ".b"]))
+                skips.append(h)
+        h = resnet("mid_block.resnets.0", h)
+        h = transformer("mid_block.attentions.0", h)
+        h = resnet("mid_block.resnets.1", h)
+        nb = len(boc)
+        rlpb = cfg.layers_per_block[::-1]
+        for i, kind in enumerate(cfg.up_block_types):
+            for j in range(rlpb[i] + 1):
+                h = resnet(f"up_blocks.{i}.resnets.{j}", h, skips.pop())
+                if kind == "CrossAttnUpBlock2D":
+                    h = transformer(f"up_blocks.{i}.attentions.{j}", h)
+            if i != nb - 1:
+                key = f"up_blocks.{i}.upsamplers.0.conv"
+                h = pb.igemm(key, h, pb.const(P[key + ".w"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]))
+        h = pb.groupnorm("conv_norm_out", h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps, True)
+        pred = pb.igemm("conv_out", h, pb.const(P["conv_out.w"]), cfg.out_channels, taps=9, bias=pb.const(P["conv_out.b"]),
+                        out_dt=L.DC_F32, tile_n=32 if cfg.out_channels <= 32 else 128)
+        if pred.dom != "unit":
+            raise L.DcamdError("backbone has no class-conditioned layer: nothing to score per class")
+        self.pred = pred
+        if score is not None:
+            pb.eps_mse(pred, eps_t, pb.const(score["x"]), al, sg, pb.const(self.bj_of_unit), pb.const(score["img_of_bj"]),
+                       pb.const(score["out_index"]), pb.const(score["errors"]), cfg.in_channels, score["v_param"])
+        pb.finalize(keep_alive=[pred])
+
+    def run(self):
+        self.pb.run()
+
+    def pred_view(self):
+        return self.pb.tensor_view(self.pred)
+
+    @property
+    def arena_bytes(self):
+        return self.pb.arena_bytes

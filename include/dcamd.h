@@ -1,0 +1,168 @@
+/* dcamd.h — C-ABI of the MI355X (gfx950) diffusion-classifier scoring path.
+ *
+ * One shared library, libdcamd.so, plain C entry points, plain pointers and sizes, no
+ * torch types.  Every entry point enqueues HIP kernels on the caller's stream and
+ * returns; nothing allocates, frees or synchronises.  The caller owns every buffer.
+ *
+ * What each entry point replaces in the reference (faverogian/diffusion-classifier):
+ *   dc_qsample          diffusion/diffusion_classifier.py:100-117 (diffuse) + :690-692
+ *   dc_philox_normal    torch.randn_like at diffusion_classifier.py:113 (throughput mode)
+ *   dc_sinusoid         diffusers Timesteps behind nets/unet.py:187 / nets/dit.py:50
+ *   dc_igemm            every Conv2d 3x3/1x1 and Linear of the diffusers backbone behind
+ *                       nets/unet.py:186-195 and nets/dit.py:49-51 (implicit GEMM on MFMA)
+ *   dc_groupnorm        GroupNorm(+SiLU) sites of ResnetBlock2D / Transformer2DModel
+ *   dc_layernorm        LayerNorm sites of BasicTransformerBlock; adaLN-Zero modulate (DiT)
+ *   dc_attention        F.scaled_dot_product_attention self-attention (attn1)
+ *   dc_eps_mse          diffusion_classifier.py:706-711 (v->eps, torch.norm(...)**2)
+ *   dc_haar_dwt2/idwt2  utils/wavelet.py:4-35 / :37-68
+ *   dc_run_plan         the Python double loop body, diffusion_classifier.py:695-714, as
+ *                       one native launch sequence (graph-capturable)
+ *
+ * Errors: 0 = ok; negative dc_status otherwise; text via dc_last_error() (thread-local).
+ * No exception crosses the ABI.  HIP launch errors are returned as DC_ERR_LAUNCH.
+ */
+#ifndef DCAMD_H
+#define DCAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_ABI_VERSION 1
+
+typedef void* dc_stream; /* hipStream_t */
+
+typedef enum { DC_OK = 0, DC_ERR_ARG = -1, DC_ERR_SHAPE = -2, DC_ERR_DTYPE = -3,
+               DC_ERR_ALIGN = -4, DC_ERR_LAUNCH = -5, DC_ERR_UNSUPPORTED = -6 } dc_status;
+
+typedef enum { DC_F32 = 0, DC_BF16 = 1, DC_F16 = 2 } dc_dtype;
+
+typedef enum { DC_ACT_NONE = 0, DC_ACT_SILU = 1, DC_ACT_GEGLU = 2, DC_ACT_GELU_TANH = 3 } dc_act;
+
+int dc_abi_version(void);
+const char* dc_last_error(void);
+/* "gfx950" — the only code object in the library. */
+const char* dc_arch(void);
+
+/* ---------------------------------------------------------------- q_sample ------- */
+/* z[bj] = alpha[bj]*x[img[bj]] + sigma[bj]*eps[bj]          (reference :115)
+ * x   [n_img, C, H, W] f32 NCHW;  eps [n_bj, C, H, W] f32 NCHW.
+ * out: im2col==0: z as NHWC [n_bj, H, W, ld] (channels >= C are written as zero)
+ *      im2col==1: 3x3 zero-padded patches [n_bj, H, W, ld], k = tap*C + c for
+ *                 tap = ky*3+kx, k in [9C, ld) zero — the A operand of conv_in as a GEMM.
+ * out_dtype: DC_F32 / DC_BF16 / DC_F16. */
+typedef struct {
+  const float* x; const float* eps; const float* alpha; const float* sigma;
+  const int32_t* img_of_bj; /* [n_bj] or NULL (identity) */
+  void* out; int32_t out_dtype;
+  int32_t n_bj, C, H, W, ld, im2col;
+  int32_t patch;            /* im2col==2: non-overlapping patch x patch tokens [n_bj, H/p, W/p, ld],
+                               k = c*p*p + py*p + px (the A operand of DiT's patch embedding) */
+} dc_qsample_params;
+int dc_qsample(const dc_qsample_params* p, dc_stream s);
+
+/* out[r, i] ~ N(0,1) for r < rows, i < row_len (multiple of 4): Philox4x32-10 with key = seed and
+ * counter = row_ids[r]*(row_len/4) + i/4 (row_ids NULL: r), Box-Muller.  The value of a row
+ * depends only on (seed, row id), so sharding rows across GPUs never changes the noise. */
+int dc_philox_normal(float* out, int64_t rows, int64_t row_len, const int64_t* row_ids, uint64_t seed, dc_stream s);
+
+/* ---------------------------------------------------------------- sinusoid ------- */
+/* emb[i, :] = [cos(lam_i*w_k), sin(lam_i*w_k)] (flip) or [sin, cos]; w_k = exp(-ln(1e4)*k/(half-shift)) */
+typedef struct { const float* lam; float* out; int32_t n, dim, flip_sin_to_cos; float freq_shift; } dc_sinusoid_params;
+int dc_sinusoid(const dc_sinusoid_params* p, dc_stream s);
+
+/* ---------------------------------------------------------------- igemm ---------- */
+/* Implicit GEMM on MFMA: conv 3x3 (pad 1, stride 1|2, optional nearest-2x upsample folded
+ * into the gather, optional channel-concat of two sources) or a plain GEMM / 1x1 conv
+ * (taps = 1).  Activations are NHWC: rows = n_img*Hout*Wout, K = taps*(C0+C1).
+ *   out[row, co] = epilogue( sum_k A[row,k] * Wp[co,k] )
+ * epilogue: (+bias[co]) (+rowvec[vmap[n]][co]) -> act -> (*gate[gmap[n]][co]) (+residual[row,co])
+ * A/W dtype = dtype (f32 uses v_mfma_f32_16x16x4_f32; bf16/f16 use 16x16x32).
+ * W is packed [Cout_pad][K] (K contiguous, k = tap*(C0+C1) + c), Cout_pad = multiple of the
+ * kernel's N tile (dc_igemm_cout_pad), zero filled.  For DC_ACT_GEGLU the packed rows
+ * interleave 16-row blocks of the value half and the gate half (see dc_igemm docs in
+ * DESIGN.md) and the output has Cout/2 channels.
+ * Constraints: C0, C1 multiples of 128/sizeof(dtype) elements (32 f32 / 64 bf16,f16). */
+typedef struct {
+  int32_t dtype, taps, stride, upsample;
+  int32_t n_img, Hin, Win, Hout, Wout;      /* Hin/Win: conv input size AFTER upsample */
+  const void* src0; const int32_t* map0; int32_t C0, ld0;  /* ld: pixel stride in elements (0: = C) */
+  const void* src1; const int32_t* map1; int32_t C1, ld1;
+  const void* W; int32_t Cout, tile_n;      /* tile_n: 128 or 32 (packing granularity) */
+  const float* bias;
+  const float* rowvec; const int32_t* rowvec_map; int32_t rowvec_ld, act;
+  const float* gate; const int32_t* gate_map; int32_t gate_ld, pad2_;
+  const void* residual; const int32_t* res_map; int32_t res_dtype, res_ld;
+  void* out; int32_t out_dtype, out_ld;
+} dc_igemm_params;
+int dc_igemm(const dc_igemm_params* p, dc_stream s);
+int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
+
+/* ---------------------------------------------------------------- norms ---------- */
+/* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.
+ * ws: float workspace >= dc_groupnorm_ws_floats(n, groups, splits). */
+typedef struct {
+  const void* x; const int32_t* map0;   /* source 0: [*, HW, C] ; map: sample -> source sample or NULL */
+  const void* x1; const int32_t* map1;  /* optional source 1 (channel concat after source 0), C1 channels */
+  void* y; int32_t dtype, out_dtype;    /* y: [n, HW, C+C1] */
+  int32_t n, HW, C, C1, groups, silu, splits; float eps;
+  const float* gamma; const float* beta; float* ws;
+} dc_groupnorm_params;
+int dc_groupnorm(const dc_groupnorm_params* p, dc_stream s);
+int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t splits);
+int32_t dc_groupnorm_splits(int32_t n, int32_t HW, int32_t C);
+
+/* LayerNorm over C per row. gamma/beta may be NULL.  If scale/shift given (adaLN):
+ * y = ln(x)*(1+scale[m[n]][c]) + shift[m[n]][c], n = row / rows_per_sample. */
+typedef struct {
+  const void* x; void* y; int32_t dtype, out_dtype;
+  int32_t rows, C, rows_per_sample, mod_ld; float eps;
+  const float* gamma; const float* beta;
+  const float* scale; const float* shift; const int32_t* mod_map;
+} dc_layernorm_params;
+int dc_layernorm(const dc_layernorm_params* p, dc_stream s);
+
+/* ---------------------------------------------------------------- attention ------ */
+/* softmax(q k^T * scale) v per (sample, head).  q/k/v: [n, L, heads, d] with row stride
+ * ld (elements) so a fused QKV GEMM output can be passed as three offset pointers. */
+typedef struct {
+  const void* q; const void* k; const void* v; void* out;
+  int32_t dtype, n, L, heads, d, ld_qkv, ld_out; float scale;
+} dc_attention_params;
+int dc_attention(const dc_attention_params* p, dc_stream s);
+
+/* ---------------------------------------------------------------- eps-MSE -------- */
+/* err[u] = (|| eps_hat_u - eps_{bj(u)} ||_2)^2 over C*H*W   (reference :706-711)
+ * pred [n_units, H, W, ld] f32 NHWC; eps [n_bj,C,H,W], x [n_img,C,H,W] f32 NCHW.
+ * v_param: eps_hat = sigma*z + alpha*pred with z = alpha*x + sigma*eps (fp32), else pred.
+ * out_index: err is stored at out[out_index[u]] (NULL: out[u]). Deterministic reduction. */
+typedef struct {
+  const float* pred; const float* eps; const float* x; const float* alpha; const float* sigma;
+  const int32_t* bj_of_unit; const int32_t* img_of_bj; const int32_t* out_index;
+  float* out; int32_t n_units, C, H, W, ld, v_param;
+  int32_t patch;            /* >1: pred is DiT's un-patchified projection [n_units, H/p, W/p, ld] with
+                               k = (py*p+px)*C + c (nets/dit.py un-patchify folded into the read) */
+} dc_eps_mse_params;
+int dc_eps_mse(const dc_eps_mse_params* p, dc_stream s);
+
+/* ---------------------------------------------------------------- Haar ----------- */
+/* in [n, C, H, W] f32 -> out [n, 4C, H/2, W/2], channel 4i+{0,1,2,3} = cA,cH,cV,cD; out*=scale */
+int dc_haar_dwt2(const float* in, float* out, int32_t n, int32_t C, int32_t H, int32_t W, float scale, dc_stream s);
+/* in [n, 4C, h, w] -> out [n, C, 2h, 2w] */
+int dc_haar_idwt2(const float* in, float* out, int32_t n, int32_t C, int32_t h, int32_t w, float scale, dc_stream s);
+
+/* ---------------------------------------------------------------- plan ----------- */
+typedef enum { DC_OP_QSAMPLE = 1, DC_OP_SINUSOID = 2, DC_OP_IGEMM = 3, DC_OP_GROUPNORM = 4,
+               DC_OP_LAYERNORM = 5, DC_OP_ATTENTION = 6, DC_OP_EPS_MSE = 7 } dc_op_kind;
+typedef struct { int32_t kind; int32_t pad_; const void* params; } dc_op;
+/* Launch ops[0..n) in order on the stream; stops at the first failure and returns its
+ * status (failed index via dc_last_error text). */
+int dc_run_plan(const dc_op* ops, int32_t n, dc_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCAMD_H */
