@@ -132,10 +132,12 @@ extern "C" int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t spl
   return (int64_t)n * groups * splits * 2;
 }
 extern "C" int32_t dc_groupnorm_splits(int32_t n, int32_t HW, int32_t C) {
-  // aim for >= ~2048 workgroups (256 CUs x 8) with >= 32 pixels each
-  int s = 1;
-  while ((long long)n * s < 2048 && HW / (s * 2) >= 32) s *= 2;
-  return s;
+  // A function of the spatial size ONLY: the split count fixes the summation order of the
+  // statistics, and scores must not depend on how many samples share a launch (micro-batch size,
+  // world size).  256 pixels per workgroup, at most 64 splits.
+  (void)n; (void)C;
+  int s = HW / 256;
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
 }
 
 extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {

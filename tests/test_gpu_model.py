@@ -1,0 +1,200 @@
+"""GPU: whole-backbone and whole-classify parity of the HIP path against the CPU oracle.
+
+Bars (BASELINE.json north_star): fp32 path — per-class eps-MSE within 1e-4 relative of the CPU
+PyTorch path and bit-exact arg-min labels.  bf16/f16 paths — compared with the oracle run with
+the SAME storage rounding (`lowp=True`), tolerance stated per test, plus label agreement.
+"""
+import numpy as np
+import pytest
+import torch
+
+import diffusion_classifier_amd as dca
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_pair(kw, seed=0, lowp=False):
+    torch.manual_seed(seed)
+    m = dca.UNetCondition2D(**kw)
+    # default inits leave GroupNorm/LayerNorm affine at (1,0) and biases tiny: randomise them so the
+    # test can see a swapped gamma/beta or a dropped bias
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    o = oracle.OracleUNetCondition2D(**kw, lowp=lowp)
+    o.load_state_dict(m.state_dict())
+    return m, o
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_small_unet_forward_f32(share):
+    kw = dca.small_unet_kwargs()
+    m, o = make_pair(kw)
+    torch.manual_seed(1)
+    N = 5
+    x, lam, emb = torch.randn(N, 3, 32, 32), torch.tensor([14.9, 2.0, 0.0, -3.0, -14.0]), torch.randn(N, 1, 64)
+    ref = o(x, lam, encoder_hidden_states=emb)
+    m = m.to(DEV)
+    m.share_trunk = share
+    got = m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    assert got.shape == ref.shape
+    assert relerr(got, ref) < 2e-5, relerr(got, ref)
+    assert (got - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtname,tol", [("bf16", 1.5e-2), ("f16", 2.5e-3)])
+def test_small_unet_forward_lowp(dtname, tol):
+    kw = dca.small_unet_kwargs()
+    m, o = make_pair(kw, lowp=True)
+    if dtname == "f16":
+        o._q = lambda t: t.to(torch.float16).float()
+    torch.manual_seed(2)
+    N = 4
+    x, lam, emb = torch.randn(N, 3, 32, 32), torch.tensor([5.0, 1.0, -1.0, -8.0]), torch.randn(N, 1, 64)
+    ref = o(x, lam, encoder_hidden_states=emb)
+    m = m.to(DEV).set_compute_dtype(dtname)
+    got = m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    # same rounding points, fp32 accumulation in a different order -> a few low-precision ulps drift
+    assert relerr(got, ref) < tol, relerr(got, ref)
+    o32 = oracle.OracleUNetCondition2D(**kw)
+    o32.load_state_dict(o.state_dict())
+    ref32 = o32(x, lam, encoder_hidden_states=emb)
+    assert relerr(got, ref32) < 4 * tol     # and it is a faithful low-precision version of the fp32 net
+
+
+def test_cifar_unet_forward_f32():
+    """BASELINE config-2 architecture (experiments/cifar10/inference.py:94-116), one forward."""
+    kw = dca.cifar10_unet_kwargs()
+    m, o = make_pair(kw, seed=3)
+    torch.manual_seed(4)
+    N = 2
+    x, lam, emb = torch.randn(N, 3, 32, 32), torch.tensor([3.0, -2.0]), torch.randn(N, 1, 128)
+    ref = o(x, lam, encoder_hidden_states=emb)
+    m = m.to(DEV)
+    got = m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    assert relerr(got, ref) < 3e-5, relerr(got, ref)
+
+
+def test_one_token_cross_attention_shortcut_is_exact():
+    """attn2 over a single class token == to_out(to_v(ctx)) for every query (what the engine uses)."""
+    kw = dca.small_unet_kwargs()
+    _, o = make_pair(kw, seed=5)
+    t = o.mid_block.attentions[0]
+    torch.manual_seed(6)
+    h, ctx = torch.randn(3, 16, 128), torch.randn(3, 1, 64)
+    full = o.cross_attn_exact(t, h, ctx)
+    a2 = t.transformer_blocks[0].attn2
+    short = a2.to_out[0](a2.to_v(ctx[:, 0]))[:, None, :].expand_as(full)
+    assert (full - short).abs().max().item() < 1e-6
+
+
+def _classifiers(kw, cfg, seed=0, lowp=False):
+    m, o = make_pair(kw, seed=seed, lowp=lowp)
+    dc = dca.DiffusionClassifier(m, dca.Config(**cfg))
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    if dc.encoder is not None:
+        oc.encoder.load_state_dict(dc.encoder.state_dict())
+    return dc.to(DEV), oc
+
+
+BASE = dict(pred_param="eps", schedule="cosine", noise_d=32, image_size=32, cfg_w=0.0, ema_beta=0.999, ema_warmup=0,
+            ema_update_freq=1, encoder_type="nn", classes=4, n_stages=1, evaluation_per_stage=[6], n_keep_per_stage=[1],
+            n_fast_classes=2, compute_dtype="f32")
+
+
+@pytest.mark.parametrize("variant", ["eps", "v_shifted", "two_stage", "fast", "tiny_launch"])
+def test_classify_small_unet_f32_matches_oracle(variant):
+    cfg = dict(BASE)
+    fast = False
+    if variant == "v_shifted":
+        cfg.update(pred_param="v", schedule="shifted_cosine", noise_d=64)
+    if variant == "two_stage":
+        cfg.update(classes=6, n_stages=2, evaluation_per_stage=[3, 7], n_keep_per_stage=[2, 1])
+    if variant == "fast":
+        cfg.update(classes=6, n_fast_classes=3)
+        fast = True
+    if variant == "tiny_launch":
+        cfg.update(units_per_launch=7)        # ragged micro-batches with padding rows
+    dc, oc = _classifiers(dca.small_unet_kwargs(), cfg, seed=7)
+    torch.manual_seed(8)
+    BS, T = 3, cfg["evaluation_per_stage"][-1]
+    x = torch.rand(BS, 3, 32, 32) * 2 - 1
+    t, eps = torch.rand(T, BS), torch.randn(T, BS, 3, 32, 32)
+    lab = torch.randint(0, cfg["classes"], (BS,))
+    sel = torch.randint(0, cfg["classes"] - 1, (BS, cfg["n_fast_classes"] - 1)) if fast else None
+    ref_l, ref_e = oc.classify(x, lab if fast else None, fast=fast, t=t, eps=eps, fast_select=sel, return_errors=True)
+    got_l, got_e = dc.classify(x.to(DEV), lab.to(DEV) if fast else None, fast=fast, t=t, eps=eps.to(DEV), fast_select=sel,
+                               return_errors=True)
+    assert torch.equal(torch.isinf(got_e), torch.isinf(ref_e))          # same (class, trial) cells evaluated
+    fin = torch.isfinite(ref_e)
+    rel = ((got_e[fin] - ref_e[fin]).abs() / ref_e[fin]).max().item()
+    assert rel < 1e-4, rel                                              # north-star bar: per-class eps-MSE within 1e-4
+    assert got_l.device.type == "cuda" and got_l.dtype == torch.int64
+    assert got_l.cpu().tolist() == ref_l.tolist()                       # bit-exact arg-min labels
+
+
+def test_classify_bf16_against_lowp_oracle():
+    cfg = dict(BASE, compute_dtype="bf16", evaluation_per_stage=[4])
+    dc, oc = _classifiers(dca.small_unet_kwargs(), cfg, seed=9, lowp=True)
+    torch.manual_seed(10)
+    BS, T = 3, 4
+    x = torch.rand(BS, 3, 32, 32) * 2 - 1
+    t, eps = torch.rand(T, BS), torch.randn(T, BS, 3, 32, 32)
+    ref_l, ref_e = oc.classify(x, t=t, eps=eps, return_errors=True)
+    got_l, got_e = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    rel = ((got_e - ref_e).abs() / ref_e).max().item()
+    assert rel < 2e-2, rel               # bf16 storage (2^-8) at identical rounding points; fp32 accumulate
+    means_g, means_r = got_e.mean(2), ref_e.mean(2)
+    gap = (means_r.sort(1).values[:, 1] - means_r.sort(1).values[:, 0]) / means_r.min(1).values
+    decided = gap > 5e-2                 # only well-separated images must agree at bf16
+    assert (got_l.cpu()[decided] == ref_l[decided]).all()
+
+
+def test_classify_philox_is_world_size_and_launch_size_independent():
+    cfg = dict(BASE, evaluation_per_stage=[5])
+    dc, _ = _classifiers(dca.small_unet_kwargs(), cfg, seed=11)
+    torch.manual_seed(12)
+    x = (torch.rand(2, 3, 32, 32) * 2 - 1).to(DEV)
+    t = torch.rand(5, 2)
+    l1, e1 = dc.classify(x, t=t, rng="philox", seed=99, return_errors=True)
+    dc.config.units_per_launch = 8
+    l2, e2 = dc.classify(x, t=t, rng="philox", seed=99, return_errors=True)
+    assert torch.equal(e1, e2) and torch.equal(l1, l2)    # same (seed, image, trial) noise and same kernels -> bit-identical
+    l3, e3 = dc.classify(x, t=t, rng="philox", seed=100, return_errors=True)
+    assert not torch.equal(e1, e3)
+
+
+def test_small_dit_forward_and_classify_f32():
+    kw = dict(num_attention_heads=2, attention_head_dim=32, in_channels=4, num_layers=2, sample_size=16, patch_size=4,
+              num_embeds_ada_norm=10)
+    torch.manual_seed(13)
+    m = dca.DiT(**kw)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    o = oracle.OracleDiT(**kw)
+    o.load_state_dict(m.state_dict())
+    N = 3
+    x, lam, lab = torch.randn(N, 4, 16, 16), torch.tensor([4.0, 0.0, -6.0]), torch.tensor([1, 9, 3])
+    ref = o(x, lam, lab)
+    md = m.to(DEV)
+    got = md(x.to(DEV), lam.to(DEV), lab.to(DEV)).cpu()
+    assert relerr(got, ref) < 2e-5, relerr(got, ref)
+    cfg = dict(BASE, encoder_type="DiT", classes=3, evaluation_per_stage=[4], image_size=16, noise_d=16)
+    dc = dca.DiffusionClassifier(m.cpu(), dca.Config(**cfg)).to(DEV)
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    BS, T = 2, 4
+    xx = torch.rand(BS, 4, 16, 16) * 2 - 1
+    t, eps = torch.rand(T, BS), torch.randn(T, BS, 4, 16, 16)
+    ref_l, ref_e = oc.classify(xx, t=t, eps=eps, return_errors=True)
+    got_l, got_e = dc.classify(xx.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    assert ((got_e - ref_e).abs() / ref_e).max().item() < 1e-4
+    assert got_l.cpu().tolist() == ref_l.tolist()

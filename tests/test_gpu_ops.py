@@ -1,0 +1,375 @@
+"""GPU: every HIP kernel of libdcamd, called through the C-ABI, against a plain PyTorch fp32
+reference of the same op on the CPU (and pywt goldens for Haar).  Tolerances are written next
+to each check: fp32 kernels must agree to ~1e-5 relative (different summation order only);
+bf16/f16 kernels are compared with the SAME rounded inputs and fp32 accumulation, so only the
+output rounding (2^-8 bf16, 2^-11 f16) remains."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import diffusion_classifier_amd as dca
+from diffusion_classifier_amd import _lib as L
+from diffusion_classifier_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TD = {L.DC_F32: torch.float32, L.DC_BF16: torch.bfloat16, L.DC_F16: torch.float16}
+TOL = {L.DC_F32: 2e-5, L.DC_BF16: 1.2e-2, L.DC_F16: 2e-3}
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def maxrel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(TD[dt]).to(DEV)
+
+
+def run_igemm(**kw):
+    p = L.IgemmParams(**kw)
+    L.check(L.lib().dc_igemm(p, L.stream_ptr()), "dc_igemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("case", ["plain", "stride2", "upsample", "concat", "maps", "small_n", "ragged_m"])
+def test_conv3x3(dt, case):
+    torch.manual_seed(1)
+    g = E.bke(dt)
+    N, H, W, C0, C1, Cout, stride, up = 3, 8, 8, 2 * g, 0, 128, 1, 0
+    tile_n = 128
+    if case == "stride2":
+        stride = 2
+    if case == "upsample":
+        up = 1
+    if case == "concat":
+        C1 = g
+    if case == "small_n":
+        Cout, tile_n = 3, 32
+    if case == "ragged_m":
+        N, H, W, Cout = 5, 6, 10, 200   # M = 300 (not a tile multiple), Cout not a tile multiple
+    q = lambda t: t.to(TD[dt]).float()
+    x0 = q(torch.randn(N, C0, H, W))
+    x1 = q(torch.randn(N, C1, H, W)) if C1 else None
+    w = q(torch.randn(Cout, C0 + C1, 3, 3) / (3 * (C0 + C1) ** 0.5))
+    b = torch.randn(Cout)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    n_out, map0 = N, None
+    if case == "maps":
+        n_out = 7
+        m = torch.tensor([2, 0, 1, 1, 2, 0, 0], dtype=torch.int32)
+        xin = xin[m.long()]
+        map0 = m.to(DEV)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    Hin, Win = xin.shape[2:]
+    Ho, Wo = ref.shape[2:]
+    rv = torch.randn(n_out, Cout)
+    res = q(torch.randn(n_out, Cout, Ho, Wo))
+    ref = ref + rv[:, :, None, None] + res
+    Wp = E.pack_conv3x3(w, dt, DEV, tile_n)
+    out = torch.full((n_out, Ho, Wo, Cout), float("nan"), dtype=TD[dt], device=DEV)
+    a0, a1 = nhwc(x0, dt), (nhwc(x1, dt) if C1 else None)
+    bd, rvd, resd = b.to(DEV), rv.to(DEV).contiguous(), nhwc(res, dt)
+    run_igemm(dtype=dt, taps=9, stride=stride, upsample=up, n_img=n_out, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo,
+              src0=ptr(a0), map0=ptr(map0), C0=C0, ld0=0, src1=ptr(a1), map1=ptr(map0) if C1 else None, C1=C1, ld1=0,
+              W=ptr(Wp), Cout=Cout, tile_n=tile_n, bias=ptr(bd), rowvec=ptr(rvd), rowvec_map=None, rowvec_ld=Cout,
+              act=L.ACT_NONE, residual=ptr(resd), res_map=None, res_dtype=dt, res_ld=Cout,
+              out=ptr(out), out_dtype=dt, out_ld=Cout)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert maxrel(got, ref) < TOL[dt], (case, maxrel(got, ref))
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH, L.ACT_GEGLU])
+def test_gemm_epilogues(dt, act):
+    torch.manual_seed(2)
+    g = E.bke(dt)
+    rows_per, n, K, Nn = 20, 9, 3 * g, 256
+    q = lambda t: t.to(TD[dt]).float()
+    a = q(torch.randn(n * rows_per, K))
+    w = q(torch.randn(Nn, K) / K ** 0.5)
+    b = torch.randn(Nn)
+    gate = torch.randn(4, Nn)
+    gmap = torch.randint(0, 4, (n,), dtype=torch.int32)
+    y = a @ w.t() + b
+    if act == L.ACT_SILU:
+        y = F.silu(y)
+    elif act == L.ACT_GELU_TANH:
+        y = F.gelu(y, approximate="tanh")
+    if act == L.ACT_GEGLU:
+        u, gg = y.chunk(2, dim=-1)
+        y = u * F.gelu(gg)
+        perm = E.geglu_perm(Nn // 2)
+        Wp, bp = E.pack_matrix(w[perm], dt, DEV), b[perm].contiguous().to(DEV)
+        n_out = Nn // 2
+        gate_d = None
+    else:
+        y = y * gate[gmap.long()].repeat_interleave(rows_per, 0)
+        Wp, bp, n_out = E.pack_matrix(w, dt, DEV), b.to(DEV), Nn
+        gate_d = gate.to(DEV).contiguous()
+    out = torch.full((n * rows_per, n_out), float("nan"), dtype=torch.float32, device=DEV)
+    ad = a.to(TD[dt]).to(DEV)
+    gm = gmap.to(DEV)
+    run_igemm(dtype=dt, taps=1, stride=1, upsample=0, n_img=n, Hin=rows_per, Win=1, Hout=rows_per, Wout=1,
+              src0=ptr(ad), C0=K, ld0=0, C1=0, W=ptr(Wp), Cout=Nn, tile_n=128, bias=ptr(bp), act=act,
+              gate=ptr(gate_d), gate_map=ptr(gm) if gate_d is not None else None, gate_ld=Nn,
+              out=ptr(out), out_dtype=L.DC_F32, out_ld=n_out)
+    assert maxrel(out.cpu(), y) < (2e-5 if dt == L.DC_F32 else 2e-3), maxrel(out.cpu(), y)
+
+
+def test_gemm_strided_source_and_rowvec_map():
+    """ld0 > C0 (a column slice of a wider matrix) and an indexed per-sample vector."""
+    torch.manual_seed(3)
+    n, K, Kfull, Nn = 6, 64, 192, 96
+    big = torch.randn(n, Kfull)
+    w = torch.randn(Nn, K) / 8
+    table = torch.randn(5, Nn)
+    idx = torch.tensor([4, 0, 3, 3, 1, 2], dtype=torch.int32)
+    ref = big[:, 64:128] @ w.t() + table[idx.long()]
+    bigd, td, idd = big.to(DEV), table.to(DEV), idx.to(DEV)
+    Wp = E.pack_matrix(w, L.DC_F32, DEV)
+    out = torch.zeros(n, Nn, device=DEV)
+    run_igemm(dtype=L.DC_F32, taps=1, stride=1, upsample=0, n_img=n, Hin=1, Win=1, Hout=1, Wout=1,
+              src0=bigd.data_ptr() + 64 * 4, C0=K, ld0=Kfull, C1=0, W=ptr(Wp), Cout=Nn, tile_n=128,
+              rowvec=ptr(td), rowvec_map=ptr(idd), rowvec_ld=Nn, out=ptr(out), out_dtype=L.DC_F32, out_ld=Nn)
+    assert maxrel(out.cpu(), ref) < 2e-5
+
+
+def test_igemm_rejects_bad_arguments():
+    lib = L.lib()
+    x = torch.zeros(1, 4, 4, 64, device=DEV)
+    w = torch.zeros(128, 9 * 48, device=DEV)
+    p = L.IgemmParams(dtype=L.DC_F32, taps=9, stride=1, upsample=0, n_img=1, Hin=4, Win=4, Hout=4, Wout=4,
+                      src0=ptr(x), C0=48, W=ptr(w), Cout=128, tile_n=128, out=ptr(x), out_dtype=0, out_ld=128)
+    assert lib.dc_igemm(p, L.stream_ptr()) == -2 and b"C0" in lib.dc_last_error()
+    p.C0 = 64; p.Hout = 5
+    assert lib.dc_igemm(p, L.stream_ptr()) == -2
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
+@pytest.mark.parametrize("shape", [(5, 64, 128, 0, True), (3, 16, 384, 0, False), (4, 256, 256, 128, True),
+                                   (2, 4096, 128, 0, True), (3, 16, 1024, 1024, True)])
+def test_groupnorm(dt, shape):
+    n, HW, C0, C1, silu = shape
+    torch.manual_seed(4)
+    q = lambda t: t.to(TD[dt]).float()
+    Cc = C0 + C1
+    x0 = q(torch.randn(n, HW, C0) * 2 + 0.5)
+    x1 = q(torch.randn(2, HW, C1)) if C1 else None
+    m1 = torch.randint(0, 2, (n,), dtype=torch.int32)
+    xcat = torch.cat([x0, x1[m1.long()]], -1) if C1 else x0
+    gamma, beta = torch.randn(Cc), torch.randn(Cc)
+    ref = F.group_norm(xcat.permute(0, 2, 1).reshape(n, Cc, HW), 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1)
+    lib = L.lib()
+    splits = lib.dc_groupnorm_splits(n, HW, Cc)
+    ws = torch.zeros(lib.dc_groupnorm_ws_floats(n, 32, splits), device=DEV)
+    x0d = x0.to(TD[dt]).to(DEV)
+    x1d = x1.to(TD[dt]).to(DEV) if C1 else None
+    m1d = m1.to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    y = torch.full((n, HW, Cc), float("nan"), dtype=TD[dt], device=DEV)
+    p = L.GroupnormParams(x=ptr(x0d), map0=None, x1=ptr(x1d), map1=ptr(m1d) if C1 else None, y=ptr(y), dtype=dt, out_dtype=dt,
+                          n=n, HW=HW, C=C0, C1=C1, groups=32, silu=int(silu), splits=splits, eps=1e-5,
+                          gamma=ptr(gd), beta=ptr(bd), ws=ptr(ws))
+    L.check(lib.dc_groupnorm(p, L.stream_ptr()), "gn")
+    torch.cuda.synchronize()
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < (2e-4 if dt == L.DC_F32 else 6e-2), err     # outputs are O(1..8); bf16 rounding 2^-8 relative
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("C_", [64, 256, 768, 1024])
+def test_layernorm_plain_and_adaln(dt, C_):
+    torch.manual_seed(5)
+    q = lambda t: t.to(TD[dt]).float()
+    n, L_ = 3, 10
+    x = q(torch.randn(n * L_, C_) * 3 + 1)
+    gamma, beta = torch.randn(C_), torch.randn(C_)
+    lib = L.lib()
+    xd = x.to(TD[dt]).to(DEV)
+    y = torch.empty_like(xd)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    p = L.LayernormParams(x=ptr(xd), y=ptr(y), dtype=dt, out_dtype=dt, rows=n * L_, C=C_, rows_per_sample=L_, mod_ld=0,
+                          eps=1e-5, gamma=ptr(gd), beta=ptr(bd))
+    L.check(lib.dc_layernorm(p, L.stream_ptr()), "ln")
+    ref = F.layer_norm(x, (C_,), gamma, beta, 1e-5)
+    tol = {L.DC_F32: 2e-5, L.DC_BF16: 5e-2, L.DC_F16: 8e-3}[dt]
+    assert (y.float().cpu() - ref).abs().max().item() < tol
+    mod = torch.randn(4, 6 * C_)
+    mm = torch.tensor([3, 1, 1], dtype=torch.int32)
+    modd, mmd = mod.to(DEV), mm.to(DEV)
+    p = L.LayernormParams(x=ptr(xd), y=ptr(y), dtype=dt, out_dtype=dt, rows=n * L_, C=C_, rows_per_sample=L_, mod_ld=6 * C_,
+                          eps=1e-6, scale=modd.data_ptr() + C_ * 4, shift=modd.data_ptr(), mod_map=ptr(mmd))
+    L.check(lib.dc_layernorm(p, L.stream_ptr()), "ln")
+    sel = mod[mm.long()].repeat_interleave(L_, 0)
+    ref = F.layer_norm(x, (C_,), eps=1e-6) * (1 + sel[:, C_:2 * C_]) + sel[:, :C_]
+    assert (y.float().cpu() - ref).abs().max().item() < 3 * tol
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
+@pytest.mark.parametrize("Ld", [(64, 32), (16, 64), (256, 64), (64, 128), (100, 16)])
+def test_attention(dt, Ld):
+    Lq, d = Ld
+    torch.manual_seed(6)
+    n, heads = 2, 4
+    Cc = heads * d
+    q = lambda t: t.to(TD[dt]).float()
+    qkv = q(torch.randn(n, Lq, 3 * Cc))
+    sh = lambda z: z.view(n, Lq, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sh(qkv[..., :Cc]), sh(qkv[..., Cc:2 * Cc]), sh(qkv[..., 2 * Cc:]))
+    ref = ref.transpose(1, 2).reshape(n, Lq, Cc)
+    qd = qkv.to(TD[dt]).to(DEV)
+    out = torch.empty(n, Lq, Cc, dtype=TD[dt], device=DEV)
+    es = 4 if dt == L.DC_F32 else 2
+    p = L.AttentionParams(q=qd.data_ptr(), k=qd.data_ptr() + Cc * es, v=qd.data_ptr() + 2 * Cc * es, out=ptr(out), dtype=dt,
+                          n=n, L=Lq, heads=heads, d=d, ld_qkv=3 * Cc, ld_out=Cc, scale=d ** -0.5)
+    L.check(L.lib().dc_attention(p, L.stream_ptr()), "attn")
+    assert (out.float().cpu() - ref).abs().max().item() < (2e-5 if dt == L.DC_F32 else 1.5e-2)
+
+
+def test_attention_long_sequence_is_refused_loudly():
+    x = torch.zeros(1, device=DEV)
+    p = L.AttentionParams(q=ptr(x), k=ptr(x), v=ptr(x), out=ptr(x), dtype=0, n=1, L=4096, heads=1, d=64, ld_qkv=192, ld_out=64, scale=1)
+    rc = L.lib().dc_attention(p, L.stream_ptr())
+    assert rc in (0, -6)   # -6 until the long-sequence kernel exists; never a silent wrong answer
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_qsample_layouts(dt, mode):
+    torch.manual_seed(7)
+    B, n_bj, Cc, H, W = 3, 5, 3, 8, 8
+    x, eps = torch.rand(B, Cc, H, W) * 2 - 1, torch.randn(n_bj, Cc, H, W)
+    al, sg = torch.rand(n_bj), torch.rand(n_bj)
+    img = torch.tensor([0, 2, 1, 1, 0], dtype=torch.int32)
+    z = al.view(-1, 1, 1, 1) * x[img.long()] + sg.view(-1, 1, 1, 1) * eps
+    pch = 4
+    if mode == 0:
+        ld, ref = 64, torch.zeros(n_bj, H, W, 64)
+        ref[..., :Cc] = z.permute(0, 2, 3, 1)
+    elif mode == 1:
+        ld = 64
+        cols = F.unfold(z, 3, padding=1).view(n_bj, Cc, 9, H, W)      # [n, c, tap, H, W]
+        ref = torch.zeros(n_bj, H, W, ld)
+        ref[..., :27] = cols.permute(0, 3, 4, 2, 1).reshape(n_bj, H, W, 27)   # k = tap*C + c
+    else:
+        ld = 64
+        cols = F.unfold(z, pch, stride=pch).view(n_bj, Cc * pch * pch, H // pch, W // pch)   # k = c*p*p + py*p + px
+        ref = torch.zeros(n_bj, H // pch, W // pch, ld)
+        ref[..., :Cc * pch * pch] = cols.permute(0, 2, 3, 1)
+    out = torch.full(ref.shape, float("nan"), dtype=TD[dt], device=DEV)
+    xd, ed, ald, sgd, imd = x.to(DEV), eps.to(DEV), al.to(DEV), sg.to(DEV), img.to(DEV)
+    p = L.QsampleParams(x=ptr(xd), eps=ptr(ed), alpha=ptr(ald), sigma=ptr(sgd), img_of_bj=ptr(imd), out=ptr(out), out_dtype=dt,
+                        n_bj=n_bj, C=Cc, H=H, W=W, ld=ld, im2col=mode, patch=pch)
+    L.check(L.lib().dc_qsample(p, L.stream_ptr()), "qsample")
+    got = out.float().cpu()
+    assert (got - ref).abs().max().item() < (1e-6 if dt == L.DC_F32 else 2e-2)
+    if dt == L.DC_F32 and mode == 0:
+        assert torch.equal(got[..., :Cc], ref[..., :Cc]) or (got - ref).abs().max().item() < 3e-7
+
+
+@pytest.mark.parametrize("v", [0, 1])
+@pytest.mark.parametrize("patch", [0, 4])
+def test_eps_mse(v, patch):
+    torch.manual_seed(8)
+    B, n_bj, k, Cc, H, W = 2, 3, 4, 3, 8, 8
+    U = n_bj * k
+    x, eps = torch.rand(B, Cc, H, W) * 2 - 1, torch.randn(n_bj, Cc, H, W)
+    al, sg = torch.rand(n_bj) * 0.9 + 0.05, torch.rand(n_bj) * 0.9 + 0.05
+    img = torch.tensor([1, 0, 1], dtype=torch.int32)
+    bj = (torch.arange(U) // k).to(torch.int32)
+    pred = torch.randn(U, Cc, H, W)
+    a4, s4 = al[bj.long()].view(-1, 1, 1, 1), sg[bj.long()].view(-1, 1, 1, 1)
+    e = eps[bj.long()]
+    z = a4 * x[img.long()][bj.long()] + s4 * e
+    eh = s4 * z + a4 * pred if v else pred
+    ref = torch.norm((eh - e).view(U, -1), dim=1, p=2) ** 2
+    if patch:
+        g = H // patch
+        pd = pred.view(U, Cc, g, patch, g, patch).permute(0, 2, 4, 3, 5, 1).reshape(U, g, g, patch * patch * Cc).contiguous()
+        ld = patch * patch * Cc
+    else:
+        pd = pred.permute(0, 2, 3, 1).contiguous()
+        ld = Cc
+    oi = torch.randperm(U).to(torch.int32)
+    out = torch.full((U,), float("nan"), device=DEV)
+    t = [t_.to(DEV) for t_ in (pd, eps, x, al, sg, bj, img, oi)]
+    p = L.EpsMseParams(pred=ptr(t[0]), eps=ptr(t[1]), x=ptr(t[2]), alpha=ptr(t[3]), sigma=ptr(t[4]), bj_of_unit=ptr(t[5]),
+                       img_of_bj=ptr(t[6]), out_index=ptr(t[7]), out=ptr(out), n_units=U, C=Cc, H=H, W=W, ld=ld, v_param=v,
+                       patch=patch)
+    L.check(L.lib().dc_eps_mse(p, L.stream_ptr()), "mse")
+    got = out.cpu()[oi.long()]
+    assert maxrel(got, ref) < 5e-6        # same fp32 sum in a different (fixed) order
+    out2 = torch.zeros_like(out)
+    p.out = ptr(out2)
+    L.check(L.lib().dc_eps_mse(p, L.stream_ptr()), "mse")
+    assert torch.equal(out, out2)         # deterministic reduction: bit-identical run to run
+
+
+def test_sinusoid_matches_timesteps():
+    lam = torch.tensor([15.0, 1.76, 1e-7, -1.76, -14.99, 3.3])
+    for dim, flip, shift in [(128, 1, 0.0), (256, 1, 1.0), (64, 0, 0.0)]:
+        half = dim // 2
+        ex = -np.log(10000) * torch.arange(half, dtype=torch.float32) / (half - shift)
+        arg = lam[:, None] * torch.exp(ex)[None]
+        ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1) if flip else torch.cat([torch.sin(arg), torch.cos(arg)], -1)
+        ld, out = lam.to(DEV), torch.zeros(len(lam), dim, device=DEV)
+        p = L.SinusoidParams(lam=ptr(ld), out=ptr(out), n=len(lam), dim=dim, flip_sin_to_cos=flip, freq_shift=shift)
+        L.check(L.lib().dc_sinusoid(p, L.stream_ptr()), "sin")
+        assert (out.cpu() - ref).abs().max().item() < 2e-6
+
+
+def test_haar_matches_pywt_goldens_and_roundtrips():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dwt_pywt.npz"))
+    for k in ["rand_3x64x64", "rand_10x32x48", "ramp_1x4x4"]:
+        x = torch.from_numpy(g[k + ".x"])
+        dec = dca.wavelet_dec_2(x.to(DEV))
+        assert dec.device.type == "cuda" and tuple(dec.shape) == g[k + ".dec"].shape
+        scale = max(1.0, float(np.abs(g[k + ".dec"]).max()))
+        np.testing.assert_allclose(dec.cpu().numpy(), g[k + ".dec"], rtol=0, atol=2e-6 * scale)   # 1e-6 class
+        rec = dca.wavelet_enc_2(torch.from_numpy(g[k + ".dec"]).to(DEV))
+        np.testing.assert_allclose(rec.cpu().numpy(), g[k + ".enc_of_dec"], rtol=0, atol=2e-6 * scale)
+        np.testing.assert_allclose(dca.wavelet_enc_2(dec).cpu().numpy(), g[k + ".x"], rtol=0, atol=2e-6 * scale)
+    assert dca.wavelet_dec_2(torch.zeros(3, 8, 8)).device.type == "cpu"      # result lives on images.device
+    big = torch.rand(4, 3, 256, 256, device=DEV) * 2 - 1                        # CheXpert-256 shape, batched
+    rt = dca.wavelet_enc_2(dca.wavelet_dec_2(big))
+    assert (rt - big).abs().max().item() < 1e-6
+    half = dca.wavelet_dec_2(big, scale=0.5)                                    # the loaders' "/2" (dataset/chexpert.py:147)
+    assert tuple(half.shape) == (4, 12, 128, 128) and (half * 2 - dca.wavelet_dec_2(big)).abs().max().item() < 1e-6
+    with pytest.raises(L.DcamdError):
+        dca.wavelet_dec_2(torch.zeros(1, 5, 5, device=DEV))                     # odd sizes never occur in the reference
+
+
+def test_philox_normal_rows_are_keyed_by_id():
+    lib = L.lib()
+    rows, n = 6, 4096
+    ids = torch.tensor([5, 0, 3, 3, 100, 1], dtype=torch.int64, device=DEV)
+    a = torch.zeros(rows, n, device=DEV)
+    L.check(lib.dc_philox_normal(ptr(a), rows, n, ptr(ids), 1234, L.stream_ptr()), "philox")
+    b = torch.zeros(2, n, device=DEV)
+    ids2 = torch.tensor([3, 5], dtype=torch.int64, device=DEV)
+    L.check(lib.dc_philox_normal(ptr(b), 2, n, ptr(ids2), 1234, L.stream_ptr()), "philox")
+    assert torch.equal(a[2], a[3]) and torch.equal(b[0], a[2]) and torch.equal(b[1], a[0])   # value depends on (seed,id) only
+    assert not torch.equal(a[0], a[1])
+    big = torch.zeros(64, 65536, device=DEV)
+    L.check(lib.dc_philox_normal(ptr(big), 64, 65536, None, 7, L.stream_ptr()), "philox")
+    assert abs(big.mean().item()) < 3e-3 and abs(big.std().item() - 1) < 3e-3
+    assert abs((big ** 4).mean().item() - 3.0) < 0.05
