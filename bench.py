@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — images classified / sec of the diffusion-classifier scoring path on MI355X.
+
+A "step" = one `DiffusionClassifier.classify` call over one batch of synthetic images already
+resident in HBM (BASELINE.json metric; default workload = config 2: CIFAR-10 32x32 UNet of
+reference experiments/cifar10/inference.py:94-116, 10 classes x 50 trials, bf16).
+  python bench.py --gpus N --steps K --warmup W
+N>1: launched by torch.distributed.run, one rank per GPU; the (trial, image) pairs of the step
+are sharded over the ranks, one RCCL all-gather of the error slab per step (dist.py); the global
+batch grows with N (per-GPU work fixed -> "scaling": "weak").
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel family (MFMA implicit GEMM)
+timed with HIP events on the launch stream inside the last timed step; `cpu_baseline` = the
+oracle's reference-structured loop on the host cores (N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (arch kwargs fn, encoder, classes, trials, default images per GPU per step, flop/forward)
+    "cifar10-unet-10x50": ("cifar10_unet_kwargs", "nn", 10, 50, 8, 10.454e9),
+    "small-unet-2x8": ("small_unet_kwargs", "nn", 2, 8, 8, None),
+    "chexpert256-dwt-unet-2x100": ("chexpert_dwt_unet_kwargs", "nn", 2, 100, 2, 176.47e9),
+    "ipmsa5-unet-5x200": ("ipmsa5_unet_kwargs", "nn", 5, 200, 1, 634.96e9),
+    "chexpert256-dwt-dit-b4-2x250": ("chexpert_dit_b4_kwargs", "DiT", 2, 250, 2, 213.31e9),
+}
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cifar10-unet-10x50", choices=list(WORKLOADS))
+    ap.add_argument("--images-per-gpu", type=int, default=None)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--units-per-launch", type=int, default=None)
+    ap.add_argument("--no-share-trunk", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default=None, help="write the per-op event timings of the last step to this JSON file")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import diffusion_classifier_amd as dca
+    arch_fn, enc, classes, T, ipg, flop_fwd = WORKLOADS[args.workload]
+    ipg = args.images_per_gpu or ipg
+    kw = getattr(dca, arch_fn)()
+    torch.manual_seed(0)
+    backbone = dca.UNetCondition2D(**kw) if enc == "nn" else dca.DiT(**kw)
+    size, cin = kw["sample_size"], kw["in_channels"]
+    cfg = dict(pred_param="eps", schedule="cosine", noise_d=size, image_size=size, cfg_w=0.0, ema_beta=0.999, ema_warmup=0,
+               ema_update_freq=1, encoder_type=enc, classes=classes, n_stages=1, evaluation_per_stage=[T],
+               n_keep_per_stage=[1], n_fast_classes=2, fast_classification=False, compute_dtype=args.dtype,
+               units_per_launch=args.units_per_launch)
+    dc = dca.DiffusionClassifier(backbone, dca.Config(**cfg))
+    dc.ema.ema_model.share_trunk = not args.no_share_trunk
+    dc = dc.to(dev)
+    B = ipg * world
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(B, cin, size, size, generator=g) * 2 - 1).to(dev)       # SURVEY §8d synthetic inputs, resident in HBM
+    torch.manual_seed(1234)
+
+    def step(i):
+        return dc.classify(x, rng="philox", seed=1234 + i)
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            dc._timed_sink = []           # HIP-event pair around every op of this step, on the launch stream
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    sink, dc._timed_sink = dc._timed_sink, None
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel family, from the event timings of the last timed step ----
+    fam = {}
+    for plan, ms in sink:
+        for meta, m in zip(plan.pb.meta, ms):
+            f = fam.setdefault(meta["family"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            f["ms"] += m; f["flops"] += meta["flops"]; f["bytes"] += meta["bytes"]; f["launches"] += 1
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    d = fam[dom]
+    peak = PEAK_TFLOPS[args.dtype if "f32" not in dom else "f32"]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                    frac=round(achieved / peak, 4), traffic=None, launches=d["launches"],
+                    avg_launch_ms=round(d["ms"] / d["launches"], 5),
+                    alg_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 4))
+    total_ms = sum(v["ms"] for v in fam.values())
+    kernels = {k: dict(ms=round(v["ms"], 3), share=round(v["ms"] / total_ms, 4), launches=v["launches"],
+                       tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) if v["flops"] else None,
+                       gbps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)) for k, v in sorted(fam.items())}
+    if args.breakdown:
+        rows = []
+        for plan, ms in sink[:1]:
+            rows = [dict(meta, ms=m) for meta, m in zip(plan.pb.meta, ms)]
+        with open(args.breakdown, "w") as fh:
+            json.dump(dict(families=kernels, ops=rows), fh, indent=1)
+
+    value = B * args.steps / dt
+    rec = dict(metric="images classified/sec (node), CIFAR-10 10-class x 50-step ELBO scoring"
+               if args.workload == "cifar10-unet-10x50" else f"images classified/sec (node), {args.workload}",
+               value=round(value, 3), unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype=args.dtype, data="synthetic",
+               config=dict(workload=args.workload, images_per_step=B, classes=classes, trials=T,
+                           forwards_per_image=classes * T, share_trunk=not args.no_share_trunk,
+                           parallelism=f"grid-shard x{world}" if world > 1 else "single"),
+               roofline=roofline, kernels=kernels)
+    if flop_fwd:
+        rec["ref_equiv_tflops"] = round(value * classes * T * flop_fwd / 1e12, 1)     # reference-equivalent FLOPs
+
+    # ---- CPU baseline: the oracle's reference-structured loop on the host cores (N=1 only) ----
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle
+        ob = (oracle.OracleUNetCondition2D(**kw) if enc == "nn" else oracle.OracleDiT(**kw))
+        ob.load_state_dict(dc.model.state_dict())
+        ocfg = dict(cfg, evaluation_per_stage=[T])
+        oc = oracle.OracleDiffusionClassifier(ob, oracle.AttrBag(**ocfg))
+        if oc.encoder is not None:
+            oc.encoder.load_state_dict(dc.encoder.state_dict())
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        bs_c, tr_c = (2, 2) if size <= 32 else (1, 1)
+        xc = x[:bs_c].cpu()
+        oc.config.evaluation_per_stage = [tr_c]
+        tc = time.perf_counter()
+        oc.classify(xc)                                     # tr_c trials x all classes, sequential forwards at batch bs_c
+        el = time.perf_counter() - tc
+        cpu_val = bs_c / (el * T / tr_c)
+        rec["cpu_baseline"] = dict(value=round(cpu_val, 5), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                                   sample=f"{bs_c} images x {tr_c} of {T} trials x {classes} classes "
+                                          f"({bs_c * tr_c * classes} unit-forwards, {el:.1f} s), scaled linearly to {T} trials")
+    print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,7 +72,7 @@ class Op(C.Structure):
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
            "dc_igemm", "dc_igemm_cout_pad", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
-           "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_run_plan"]
+           "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_run_plan", "dc_run_plan_timed"]
 
 _lib = None
 
@@ -102,6 +102,7 @@ def lib():
                        ("dc_attention", [C.POINTER(AttentionParams), vp]),
                        ("dc_eps_mse", [C.POINTER(EpsMseParams), vp]),
                        ("dc_run_plan", [C.POINTER(Op), i32, vp]),
+                       ("dc_run_plan_timed", [C.POINTER(Op), i32, vp, vp]),
                        ("dc_philox_normal", [vp, i64, i64, vp, u64, vp]),
                        ("dc_haar_dwt2", [vp, vp, i32, i32, i32, i32, f32, vp]),
                        ("dc_haar_idwt2", [vp, vp, i32, i32, i32, i32, f32, vp])]:

@@ -29,9 +29,39 @@ extern "C" int dc_abi_version(void) { return DC_ABI_VERSION; }
 extern "C" const char* dc_last_error(void) { return g_err; }
 extern "C" const char* dc_arch(void) { return "gfx950"; }
 
+static int run_one(const dc_op* ops, int i, dc_stream s);
+
 extern "C" int dc_run_plan(const dc_op* ops, int32_t n, dc_stream s) {
   DC_REQUIRE(ops || n == 0, DC_ERR_ARG, "dc_run_plan: null ops");
   for (int i = 0; i < n; ++i) {
+    const int rc = run_one(ops, i, s);
+    if (rc != DC_OK) return rc;
+  }
+  return DC_OK;
+}
+
+extern "C" int dc_run_plan_timed(const dc_op* ops, int32_t n, dc_stream s, float* ms) {
+  DC_REQUIRE((ops && ms) || n == 0, DC_ERR_ARG, "dc_run_plan_timed: null ops/ms");
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  hipEvent_t* ev = new hipEvent_t[n + 1];
+  for (int i = 0; i <= n; ++i) (void)hipEventCreate(&ev[i]);
+  int rc = DC_OK;
+  (void)hipEventRecord(ev[0], st);
+  int done = 0;
+  for (; done < n; ++done) {
+    rc = run_one(ops, done, s);
+    if (rc != DC_OK) break;
+    (void)hipEventRecord(ev[done + 1], st);
+  }
+  (void)hipStreamSynchronize(st);
+  for (int i = 0; i < done; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+  for (int i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}
+
+static int run_one(const dc_op* ops, int i, dc_stream s) {
+  {
     int rc;
     switch (ops[i].kind) {
       case DC_OP_QSAMPLE: rc = dc_qsample(static_cast<const dc_qsample_params*>(ops[i].params), s); break;

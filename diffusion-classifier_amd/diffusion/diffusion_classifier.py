@@ -71,6 +71,7 @@ class DiffusionClassifier(nn.Module):
             self.null_token = self.config.classes
         print(f"Parameter count: {sum(p.numel() for p in self.model.parameters())}")
         self._score_plans = {}
+        self._timed_sink = None      # bench.py: list collecting (plan, per-op event ms) instead of plain runs
 
     # ---- small reference-identical helpers (host side, fp32 torch like the reference) -------
     def encode_text_prompt(self, text):
@@ -155,8 +156,7 @@ class DiffusionClassifier(nn.Module):
         else:
             runner = _ForeignRunner(self, backbone, x, T, draws)       # user-supplied nn.Module, eager torch
         for i in range(cfg.n_stages):
-            trials = D.local_trials(ends[i], ends[i + 1], rank, ws)
-            pairs = [(j, b) for j in trials for b in range(BS)]
+            pairs = D.local_pairs(ends[i], ends[i + 1], BS, rank, ws)
             runner.run_stage(pairs, classes)
             errors = runner.errors()
             D.gather_stage_errors(errors, ends[i], ends[i + 1], rank, ws)
@@ -349,5 +349,8 @@ class _HipRunner:
                     r = r1
                 if len(chunk) < n_bj:
                     score["eps"][len(chunk):].copy_(score["eps"][0:1].expand(n_bj - len(chunk), -1, -1, -1))
-            plan.run()
+            if dc._timed_sink is not None:
+                dc._timed_sink.append((plan, plan.pb.run_timed()))
+            else:
+                plan.run()
         torch.cuda.current_stream().synchronize()    # `host` (pinned) must outlive the async copies

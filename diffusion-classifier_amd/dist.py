@@ -1,16 +1,17 @@
 """(class x trial) grid sharding across the GPUs of one node.
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the
-CPU tests).  The trials of a stage are dealt round-robin to ranks — trial j belongs to rank
-`(j - stage_start) % world` — so every rank keeps all classes of its (image, trial) pairs local
-(q_sample and the class-shared trunk are never duplicated across ranks) and weights are
-replicated.  The ONLY data-path exchange is one all-gather of the per-rank error slab
-`[BS, classes, ceil(stage_len / world)]` per stage; every rank then holds the full
-`errors[BS, classes, T]` tensor and performs the identical fixed-order mean / top-k, so labels
-are bit-identical on all ranks and for any world size.  (An all-reduce of partial sums would
-make the result depend on the reduction order.)  The reference itself only shards the
-dataloader over ranks (diffusion_classifier.py:615-617) and all-reduces scalar metrics
-(utils/metrics.py:56-58); that outer, per-image level composes with this one.
+CPU tests).  Within a stage the (trial, image) pairs are dealt round-robin to ranks — pair
+g = (j - stage_start)*BS + b belongs to rank g % world — so every rank keeps ALL classes of its
+pairs local (q_sample and the class-shared trunk are never duplicated across ranks), the load is
+balanced to within one pair whatever T and BS are, and weights are replicated.  The ONLY
+data-path exchange is one all-gather of the per-rank error slab [ceil(P/world), classes] per
+stage (P = pairs in the stage); every rank then holds the full errors[BS, classes, T] tensor and
+performs the identical fixed-order mean / top-k, so labels are bit-identical on all ranks and
+for any world size.  (An all-reduce of partial sums would make results depend on the reduction
+order.)  The reference itself only shards the dataloader over ranks
+(diffusion_classifier.py:615-617) and all-reduces scalar metrics (utils/metrics.py:56-58);
+that outer, per-image level composes with this one.
 """
 import torch
 import torch.distributed as dist
@@ -22,31 +23,43 @@ def world():
     return 0, 1
 
 
-def local_trials(stage_start, stage_end, rank, world_size):
-    """Trials of [stage_start, stage_end) owned by `rank`."""
-    return list(range(stage_start + rank, stage_end, world_size))
+def stage_pairs(stage_start, stage_end, BS):
+    """All (trial, image) pairs of a stage, trial-major (the reference's loop order)."""
+    return [(j, b) for j in range(stage_start, stage_end) for b in range(BS)]
 
 
-def slab_len(stage_start, stage_end, world_size):
-    return -(-(stage_end - stage_start) // world_size)
+def local_pairs(stage_start, stage_end, BS, rank, world_size):
+    """Pairs of the stage owned by `rank`."""
+    return stage_pairs(stage_start, stage_end, BS)[rank::world_size]
+
+
+def slab_len(stage_start, stage_end, BS, world_size):
+    return -(-((stage_end - stage_start) * BS) // world_size)
 
 
 def gather_stage_errors(errors, stage_start, stage_end, rank, world_size, group=None):
-    """In place: fill errors[:, :, stage_start:stage_end] on every rank from the owners.
+    """In place: complete errors[:, :, stage_start:stage_end] on every rank from the owners.
 
-    `errors` is [BS, classes, T]; on entry each rank has filled only its own trials.
+    `errors` is [BS, classes, T]; on entry each rank has filled only the cells of its own pairs.
     """
     if world_size == 1:
         return errors
-    n = slab_len(stage_start, stage_end, world_size)
-    mine = local_trials(stage_start, stage_end, rank, world_size)
-    slab = torch.full((errors.shape[0], errors.shape[1], n), float("inf"), dtype=errors.dtype, device=errors.device)
+    BS, ncls = errors.shape[0], errors.shape[1]
+    n = slab_len(stage_start, stage_end, BS, world_size)
+    mine = local_pairs(stage_start, stage_end, BS, rank, world_size)
+    slab = torch.full((n, ncls), float("inf"), dtype=errors.dtype, device=errors.device)
     if mine:
-        slab[:, :, : len(mine)] = errors[:, :, mine]
-    out = torch.empty((world_size,) + tuple(slab.shape), dtype=errors.dtype, device=errors.device)
-    dist.all_gather_into_tensor(out, slab.contiguous(), group=group)
+        jj = torch.tensor([p[0] for p in mine], device=errors.device)
+        bb = torch.tensor([p[1] for p in mine], device=errors.device)
+        slab[: len(mine)] = errors[bb, :, jj]
+    flat = torch.empty((world_size * n, ncls), dtype=errors.dtype, device=errors.device)   # dim-0 concatenation (gloo needs this form)
+    dist.all_gather_into_tensor(flat, slab.contiguous(), group=group)
+    out = flat.view(world_size, n, ncls)
+    allp = stage_pairs(stage_start, stage_end, BS)
     for r in range(world_size):
-        tr = local_trials(stage_start, stage_end, r, world_size)
-        if tr:
-            errors[:, :, tr] = out[r, :, :, : len(tr)]
+        pr = allp[r::world_size]
+        if pr:
+            jj = torch.tensor([p[0] for p in pr], device=errors.device)
+            bb = torch.tensor([p[1] for p in pr], device=errors.device)
+            errors[bb, :, jj] = out[r, : len(pr)]
     return errors

@@ -63,7 +63,7 @@ class PlanBuilder:
         self.maps = {}       # (src_dom, dst_dom) -> external int32 TRef
         self.arena = None
         self.arena_bytes = 0
-        self._ws = None
+        self.meta = []       # per op: name, kernel family, algorithmic flops / HBM bytes (bench.py roofline)
 
     # ---- tensors -------------------------------------------------------------------
     def tensor(self, name, dom, H, W, Cc, dt):
@@ -98,8 +98,9 @@ class PlanBuilder:
             return "unit"
         return doms.pop()
 
-    def _emit(self, kind, cls, fields, reads, writes):
+    def _emit(self, kind, cls, fields, reads, writes, meta=None):
         idx = len(self.ops)
+        self.meta.append(dict(meta or {}, kind=kind))
         for t in reads + writes:
             if t is None:
                 continue
@@ -112,7 +113,7 @@ class PlanBuilder:
 
     # ---- ops -----------------------------------------------------------------------
     def igemm(self, name, src0, W, Cout, *, taps=1, stride=1, upsample=0, src1=None, bias=None, rowvec=None,
-              act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None):
+              act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None):
         dom = dom or self._dom(src0, src1, rowvec, gate, residual)
         Hin, Win = (src0.H * 2, src0.W * 2) if upsample else (src0.H, src0.W)
         if taps == 9:
@@ -135,7 +136,15 @@ class PlanBuilder:
                  out=out, out_dtype=out.dt, out_ld=out.ld)
         if src1 is not None:
             assert src1.dt == src0.dt and (src1.H, src1.W) == (src0.H, src0.W)
-        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual], [out])
+        M = self.n[dom] * Hout * Wout
+        kreal = taps * (src0.C + (src1.C if src1 is not None else 0)) if k_real is None else k_real
+        es = DT_SIZE[f["dtype"]]
+        nsrc = {"bj": self.n["bj"], "unit": self.n["unit"], "ctx": self.n["ctx"]}
+        in_bytes = sum(nsrc.get(t.dom, 1) * t.H * t.W * t.C * DT_SIZE[t.dt] for t in (src0, src1, residual) if t is not None)
+        meta = dict(name=name, family=f"igemm_{'f32' if f['dtype'] == L.DC_F32 else 'bf16' if f['dtype'] == L.DC_BF16 else 'f16'}_n{tile_n}",
+                    flops=2.0 * M * kreal * Cout, bytes=float(in_bytes + kreal * Cout * es + M * cout_out * DT_SIZE[out.dt]),
+                    M=M, N=Cout, K=kreal, taps=taps)
+        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual], [out], meta)
         return out
 
     def groupnorm(self, name, x0, gamma, beta, groups, eps, silu, x1=None):
@@ -150,7 +159,8 @@ class PlanBuilder:
         f = dict(x=x0, map0=self._map(x0, dom), x1=x1, map1=self._map(x1, dom), y=out, dtype=x0.dt, out_dtype=x0.dt,
                  n=n, HW=HW, C=x0.C, C1=x1.C if x1 is not None else 0, groups=groups, silu=int(silu),
                  splits=splits, eps=eps, gamma=gamma, beta=beta, ws=ws)
-        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1], [out, ws])
+        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1], [out, ws],
+                   dict(name=name, family="groupnorm", flops=0.0, bytes=2.0 * n * HW * Cc * DT_SIZE[x0.dt]))
         return out
 
     def layernorm(self, name, x, gamma, beta, eps, scale=None, shift=None):
@@ -160,7 +170,8 @@ class PlanBuilder:
         f = dict(x=x, y=out, dtype=x.dt, out_dtype=x.dt, rows=self.n[x.dom] * x.H * x.W, C=x.C,
                  rows_per_sample=x.H * x.W, mod_ld=scale.ld if scale is not None else 0, eps=eps,
                  gamma=gamma, beta=beta, scale=scale, shift=shift, mod_map=self._map(scale, x.dom))
-        self._emit(L.OP_LAYERNORM, L.LayernormParams, f, [x, scale, shift], [out])
+        self._emit(L.OP_LAYERNORM, L.LayernormParams, f, [x, scale, shift], [out],
+                   dict(name=name, family="layernorm", flops=0.0, bytes=2.0 * f["rows"] * x.C * DT_SIZE[x.dt]))
         return out
 
     def attention(self, name, q, k, v, heads):
@@ -168,13 +179,16 @@ class PlanBuilder:
         d = q.C // heads
         f = dict(q=q, k=k, v=v, out=out, dtype=q.dt, n=self.n[q.dom], L=q.H * q.W, heads=heads, d=d,
                  ld_qkv=q.ld, ld_out=out.ld, scale=float(d) ** -0.5)
-        self._emit(L.OP_ATTENTION, L.AttentionParams, f, [q, k, v], [out])
+        Lq = q.H * q.W
+        self._emit(L.OP_ATTENTION, L.AttentionParams, f, [q, k, v], [out],
+                   dict(name=name, family="attention", flops=4.0 * self.n[q.dom] * heads * Lq * Lq * d,
+                        bytes=4.0 * self.n[q.dom] * Lq * q.C * DT_SIZE[q.dt]))
         return out
 
     def sinusoid(self, name, lam, dim, flip, shift):
         out = self.tensor(name, lam.dom, 1, 1, dim, L.DC_F32)
         f = dict(lam=lam, out=out, n=self.n[lam.dom], dim=dim, flip_sin_to_cos=int(flip), freq_shift=float(shift))
-        self._emit(L.OP_SINUSOID, L.SinusoidParams, f, [lam], [out])
+        self._emit(L.OP_SINUSOID, L.SinusoidParams, f, [lam], [out], dict(name=name, family="sinusoid", flops=0.0, bytes=0.0))
         return out
 
     def qsample(self, name, x_ptr, eps, alpha, sigma, img_of_bj, Cin, H, W, ld, dt, im2col, patch=0):
@@ -182,7 +196,9 @@ class PlanBuilder:
         out = self.tensor(name, "bj", H // g, W // g, ld, dt)
         f = dict(x=x_ptr, eps=eps, alpha=alpha, sigma=sigma, img_of_bj=img_of_bj, out=out, out_dtype=dt,
                  n_bj=self.n["bj"], C=Cin, H=H, W=W, ld=ld, im2col=int(im2col), patch=int(patch))
-        self._emit(L.OP_QSAMPLE, L.QsampleParams, f, [eps, alpha, sigma], [out])
+        self._emit(L.OP_QSAMPLE, L.QsampleParams, f, [eps, alpha, sigma], [out],
+                   dict(name=name, family="qsample", flops=0.0,
+                        bytes=float(self.n["bj"] * (2 * Cin * H * W * 4 + (H // g) * (W // g) * ld * DT_SIZE[dt]))))
         return out
 
     def eps_mse(self, pred, eps, x_ptr, alpha, sigma, bj_of_unit, img_of_bj, out_index, out_ptr, Cin, v_param, patch=0):
@@ -190,7 +206,8 @@ class PlanBuilder:
         f = dict(pred=pred, eps=eps, x=x_ptr, alpha=alpha, sigma=sigma, bj_of_unit=bj_of_unit, img_of_bj=img_of_bj,
                  out_index=out_index, out=out_ptr, n_units=self.n["unit"], C=Cin, H=pred.H * g, W=pred.W * g, ld=pred.ld,
                  v_param=int(v_param), patch=int(patch))
-        self._emit(L.OP_EPS_MSE, L.EpsMseParams, f, [pred, eps, alpha, sigma], [])
+        self._emit(L.OP_EPS_MSE, L.EpsMseParams, f, [pred, eps, alpha, sigma], [],
+                   dict(name="eps_mse", family="eps_mse", flops=0.0, bytes=8.0 * self.n["unit"] * Cin * pred.H * g * pred.W * g))
 
     # ---- finalize: liveness-based arena + ctypes records ----------------------------
     def finalize(self, keep_alive=()):
@@ -272,6 +289,12 @@ class PlanBuilder:
 
     def run(self):
         L.check(L.lib().dc_run_plan(self.op_array, self.nops, L.stream_ptr()), "dc_run_plan")
+
+    def run_timed(self):
+        """Same launches with a HIP event pair around every op (on the launch stream); returns ms per op."""
+        ms = (C.c_float * self.nops)()
+        L.check(L.lib().dc_run_plan_timed(self.op_array, self.nops, L.stream_ptr(), ms), "dc_run_plan_timed")
+        return list(ms)
 
     def tensor_view(self, t):
         """torch view of an arena/external tensor (tests and the plain forward read results through it)."""
@@ -521,7 +544,7 @@ class UNetPlan:
         # share_trunk=False recomputes the class-independent layers per unit (reference-equivalent
         # executed FLOPs; used for A/B tests): conv_in then reads its operand through bj_of_unit.
         h = pb.igemm("conv_in", a0, pb.const(P["conv_in.w"]), C0, bias=pb.const(P["conv_in.b"]),
-                     dom=None if share_trunk else "unit")
+                     dom=None if share_trunk else "unit", k_real=9 * cfg.in_channels)
         skips = [h]
         boc = cfg.block_out_channels
         for i, kind in enumerate(cfg.down_block_types):

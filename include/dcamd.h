@@ -161,6 +161,9 @@ typedef struct { int32_t kind; int32_t pad_; const void* params; } dc_op;
 /* Launch ops[0..n) in order on the stream; stops at the first failure and returns its
  * status (failed index via dc_last_error text). */
 int dc_run_plan(const dc_op* ops, int32_t n, dc_stream s);
+/* Measurement variant (bench.py only): same launches bracketed by HIP events ON THE SAME STREAM;
+ * synchronises the stream at the end and writes the elapsed milliseconds of op i to ms[i]. */
+int dc_run_plan_timed(const dc_op* ops, int32_t n, dc_stream s, float* ms);
 
 #ifdef __cplusplus
 }

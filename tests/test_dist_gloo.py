@@ -1,0 +1,73 @@
+"""CPU, world_size 2 (gloo): the N>1 path of classify — pair sharding, the one all-gather per
+stage, identical labels on every rank and equal to the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import diffusion_classifier_amd as dca
+    from helpers import load_case, standin_from
+    g, cfg = load_case(name)
+    dc = dca.DiffusionClassifier(standin_from(g, cfg), dca.Config(**cfg))
+    if dc.encoder is not None:
+        dc.encoder.weight.data.copy_(torch.from_numpy(g["encoder.weight"]))
+    fast = bool(g["fast"])
+    out, err = dc.classify(torch.from_numpy(g["x"]), torch.from_numpy(g["labels"]) if fast else None, fast=fast,
+                           t=torch.from_numpy(g["t"]), eps=torch.from_numpy(g["eps"]),
+                           fast_select=torch.from_numpy(g["fast_select"]) if fast else None, return_errors=True)
+    q.put((rank, out.numpy(), err.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("2stage_pruned", 2), ("1stage_eps", 3)])
+def test_sharded_classify_equals_single_process(name, world):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import load_case
+    g, _ = load_case(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, err in res:
+        np.testing.assert_array_equal(out, g["out"])          # same labels on every rank == reference golden
+        fin = np.isfinite(g["errors"])
+        assert np.array_equal(np.isfinite(err), fin)
+        np.testing.assert_allclose(err[fin], g["errors"][fin], rtol=3e-7)   # sub-batches differ from the reference's batch of BS
+
+
+def test_pair_ownership_is_a_balanced_partition():
+    from diffusion_classifier_amd import dist as D
+    for (s0, s1, BS, world) in [(0, 50, 8, 8), (3, 10, 5, 4), (0, 1, 1, 8), (0, 100, 16, 8)]:
+        allp = D.stage_pairs(s0, s1, BS)
+        got = [D.local_pairs(s0, s1, BS, r, world) for r in range(world)]
+        assert sorted(sum(got, [])) == sorted(allp)
+        sizes = [len(x) for x in got]
+        assert max(sizes) - min(sizes) <= 1 and max(sizes) == D.slab_len(s0, s1, BS, world)
