@@ -35,6 +35,19 @@ WORKLOADS = {
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA, MI355X_MICROARCH.md
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole machine on a shared GPU box and oversubscribes badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "64"))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +95,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+        if rank == 0:
+            print(f"[bench] warmup {i + 1}/{args.warmup}", file=sys.stderr, flush=True)
 
     def fence():
         if world > 1:
@@ -153,14 +168,19 @@ def main():
         oc = oracle.OracleDiffusionClassifier(ob, oracle.AttrBag(**ocfg))
         if oc.encoder is not None:
             oc.encoder.load_state_dict(dc.encoder.state_dict())
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         torch.set_num_threads(cores)
-        bs_c, tr_c = (2, 2) if size <= 32 else (1, 1)
+        print(f"[bench] cpu baseline on {cores} host threads ...", file=sys.stderr, flush=True)
+        bs_c = 2 if size <= 32 else 1
         xc = x[:bs_c].cpu()
-        oc.config.evaluation_per_stage = [tr_c]
-        tc = time.perf_counter()
-        oc.classify(xc)                                     # tr_c trials x all classes, sequential forwards at batch bs_c
-        el = time.perf_counter() - tc
+        oc.config.evaluation_per_stage = [1]
+        el, tr_c = 0.0, 0
+        while tr_c < T and (tr_c == 0 or (el < 10.0 and el * (tr_c + 1) / tr_c < 30.0)):
+            tc = time.perf_counter()
+            oc.classify(xc)                                 # one trial x all classes, sequential forwards at batch bs_c
+            el += time.perf_counter() - tc
+            tr_c += 1
+            print(f"[bench] cpu baseline: {tr_c} trial(s) x {classes} classes in {el:.1f} s", file=sys.stderr, flush=True)
         cpu_val = bs_c / (el * T / tr_c)
         rec["cpu_baseline"] = dict(value=round(cpu_val, 5), unit="images/s", cores=torch.get_num_threads(), kind="port",
                                    sample=f"{bs_c} images x {tr_c} of {T} trials x {classes} classes "
