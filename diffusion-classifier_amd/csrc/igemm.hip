@@ -20,45 +20,8 @@
 // Block->tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) receive contiguous ranges of
 // the tile list, ordered M-fastest inside one N panel, so the workgroups sharing an L2 stream the
 // same weight panel.
-#include "common.h"
-
-struct IgemmArgs {
-  const void* src0; const int32_t* map0; const void* src1; const int32_t* map1;
-  const void* W; const float* bias;
-  const float* rowvec; const int32_t* rowvec_map;
-  const float* gate; const int32_t* gate_map;
-  const void* residual; const int32_t* res_map;
-  void* out;
-  int C0, C1, ld0, ld1, rowvec_ld, gate_ld, res_dtype, res_ld, out_dtype, out_ld, act;
-  int taps, stride, upsample, Hin, Win, Hout, Wout, Cout;
-  int M, Ktot, c0chunks, cpt, nk, tiles_m, tiles_n;
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<__bf16> {
-  static __device__ __forceinline__ f32x4 run(const chunk16 w, const chunk16 x, f32x4 acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<_Float16> {
-  static __device__ __forceinline__ f32x4 run(const chunk16 w, const chunk16 x, f32x4 acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  // Lane group q=lane>>4 holds k = 4q..4q+3 of a 16-wide k block; MFMA e consumes element e, so
-  // the four MFMAs cover all 16 k (a consistent k permutation on both operands).
-  static __device__ __forceinline__ f32x4 run(const chunk16 w, const chunk16 x, f32x4 acc) {
-    const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], xf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], xf[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], xf[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], xf[3], acc, 0, 0, 0);
-    return acc;
-  }
-};
-
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+#include <stdlib.h>
+#include "igemm_common.h"
 
 template <typename T, int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
@@ -77,15 +40,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 15, lq = lane >> 4;
 
-  // ---- XCD-aware, bijective block -> tile map ----
   int tile_m, tile_n;
-  {
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    tile_n = lid / a.tiles_m;
-    tile_m = lid - tile_n * a.tiles_m;
-  }
+  tile_of_block(a, tile_m, tile_n);
 
   const int HWo = a.Hout * a.Wout;
   const int pad = (a.taps == 9) ? 1 : 0;
@@ -180,72 +136,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds 4 consecutive couts (lq*4 + r) of pixel lr in every 16x16 tile ----
-  const bool geglu = a.act == DC_ACT_GEGLU;
-  const int cout_out = geglu ? (a.Cout >> 1) : a.Cout;
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = tile_m * BM + wm * WTM + j * 16 + lr;
-    if (m >= a.M) continue;
-    const int n = m / HWo;
-    const float* rv = a.rowvec ? a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[n] : n) * a.rowvec_ld : nullptr;
-    const float* gt = a.gate ? a.gate + (size_t)(a.gate_map ? a.gate_map[n] : n) * a.gate_ld : nullptr;
-    size_t rrow = 0;
-    if (a.residual) rrow = (a.res_map ? (size_t)a.res_map[n] * HWo + (m - n * HWo) : (size_t)m) * a.res_ld;
-    const size_t orow = (size_t)m * a.out_ld;
-#pragma unroll
-    for (int i = 0; i < TN; i += 1) {
-      const int pc = tile_n * BN + wn * WTN + i * 16 + lq * 4;  // packed channel index
-      float v[4];
-      int oc;
-      if (geglu) {
-        if (i & 1) continue;
-        oc = ((tile_n * BN + wn * WTN + i * 16) >> 1) + lq * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float val = acc[i][j][r], g = acc[(i + 1) % TN][j][r];
-          if (a.bias) { val += a.bias[pc + r]; g += a.bias[pc + 16 + r]; }
-          v[r] = val * gelu_erf_f(g);
-        }
-      } else {
-        oc = pc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = acc[i][j][r];
-          const int c = oc + r;
-          if (c < cout_out) {
-            if (a.bias) x += a.bias[c];
-            if (rv) x += rv[c];
-            if (a.act == DC_ACT_SILU) x = silu_f(x);
-            else if (a.act == DC_ACT_GELU_TANH) x = gelu_tanh_f(x);
-            if (gt) x *= gt[c];
-          }
-          v[r] = x;
-        }
-      }
-      if (oc >= cout_out) continue;
-      if (a.residual) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (oc + r < cout_out) v[r] += load_as(a.residual, rrow + oc + r, a.res_dtype);
-      }
-      if (oc + 3 < cout_out && (a.out_ld & 3) == 0) {
-        if (a.out_dtype == DC_F32) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow + oc) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (a.out_dtype == DC_BF16) {
-          __bf16 h[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-          *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + orow + oc) = *reinterpret_cast<uint2*>(h);
-        } else {
-          _Float16 h[4] = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-          *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(a.out) + orow + oc) = *reinterpret_cast<uint2*>(h);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (oc + r < cout_out) store_as(a.out, orow + oc + r, a.out_dtype, v[r]);
-      }
-    }
-  }
+  igemm_epilogue<TM, TN>(a, acc, tile_m * BM + wm * WTM, tile_n * BN + wn * WTN, lr, lq);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
@@ -319,6 +210,10 @@ extern "C" int dc_igemm(const dc_igemm_params* p, dc_stream stream) {
   a.tiles_m = (a.M + 127) / 128;
   a.tiles_n = dc_igemm_cout_pad(p->Cout, bn) / bn;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // tile_n 128: the LDS-DMA pipelined 256x128 kernel (igemm_pipe.hip).  DCAMD_IGEMM_V1=1 selects the
+  // register-staged 128x128 kernel instead (A/B measurements; same results bit for bit).
+  static const bool use_v1 = getenv("DCAMD_IGEMM_V1") != nullptr;
+  if (bn == 128 && !use_v1) return dc_igemm_launch_pipe(a, p->dtype, s);
   if (bn == 128) {
     if (p->dtype == DC_BF16) return launch<__bf16, 128, 128, 2, 2>(a, s);
     if (p->dtype == DC_F16) return launch<_Float16, 128, 128, 2, 2>(a, s);
