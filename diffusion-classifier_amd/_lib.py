@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcamd.so")
+LIB_PATH = os.environ.get("DCAMD_LIB") or os.path.join(_HERE, "libdcamd.so")   # DCAMD_LIB: diagnostic builds only
 
 DC_F32, DC_BF16, DC_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GELU_TANH = 0, 1, 2, 3

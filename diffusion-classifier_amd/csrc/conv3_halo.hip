@@ -1,0 +1,257 @@
+// conv3_halo.hip — 3x3 / stride-1 / pad-1 convolution as a halo-tile direct convolution on MFMA.
+//
+// Why: the tap-refetch implicit GEMM (igemm_pipe.hip) re-reads every input pixel 9 times from
+// L2 — rocprofv3 showed its waves parked on vmcnt/barrier 51 % of the time at ~20-30 GB/s of
+// LDS-DMA per CU.  Here LDS is the reuse level for the taps: a workgroup owns 512 output pixels
+// (nimg x th x tw patch, e.g. 16 rows x 32 of one 32x32 image) x 128 couts and, per 64-byte
+// channel chunk (32 bf16/f16 or 16 f32 channels), brings the (th+2)x(tw+2) input halo ONCE into
+// LDS; the 9 taps are just 9 different row offsets of the MFMA B-operand fragment reads.
+// HBM/L2 -> LDS traffic per 512 pixels per chunk: halo 38 KB + 9 weight tiles x 8 KB = 110 KB,
+// vs 9 x (32+8) KB = 360 KB for tap refetch.
+//
+//   X halo: double-buffered per channel chunk (the next chunk's halo is fetched during the
+//           current chunk's 9 taps); W[tap] tiles: 4-stage ring, prefetch distance 3 taps.
+//   all transfers are LDS-DMA (global_load_lds_dwordx4), counted vmcnt, one s_barrier per tap.
+//   8 waves as 4(M) x 2(N); wave tile 128 pixels x 64 couts (32 MFMA 16x16x32 per tap).
+//   padding / out-of-range images read a zero page; epilogue staged through LDS (two half passes).
+#include "igemm_epilogue.h"
+
+static __device__ chunk16 g_zero_page[16];   // per translation unit (no device-side linking)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct HaloGeom {
+  int ltw, lth, lni;        // log2 of tile width / height / images per tile (tw*th*ni == 512)
+  int tiles_x, tiles_y;     // tiles per image
+  int hw, hp, HR, nxl;      // halo width, halo pixels per image patch, halo rows per tile, X loads per lane
+  int n_img, H, W;
+};
+
+constexpr int HALO_NXL = 6;                             // LDS-DMA instructions per lane per halo (16x16 images: 2 x 18 x 18 rows)
+constexpr int HALO_XROWS_MAX = HALO_NXL * 128;
+constexpr int HALO_XBUF = HALO_NXL * 512 * 16;          // bytes per X halo buffer
+constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
+constexpr int HALO_LDS_MAIN = 2 * HALO_XBUF + 4 * HALO_WST;
+constexpr int HALO_OLD = 128 + 4;                       // epilogue staging row (floats)
+constexpr int HALO_LDS_EPI = 256 * HALO_OLD * 4;
+constexpr int HALO_LDS = HALO_LDS_MAIN > HALO_LDS_EPI ? HALO_LDS_MAIN : HALO_LDS_EPI;
+
+// 64-byte rows: 4 rows per 256-B bank row.  ds_read_b128 is served in 16-lane groups that MIX two values of
+// lane>>4 (lanes {0-3,12-15} of one quad with {20-27} of the next), so the chunk swizzle must keep
+// g(q) = [0,2,3,1][(row>>2)&3]: then the 16 rows x 2 chunks of every service group hit 16 distinct 16-B slots
+// (the plain (row>>2)&3 XOR measured 42 % of LDS cycles as bank conflicts).
+__device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+__device__ __forceinline__ int lds64_off(int row, int chunk) { return row * 64 + ((chunk ^ swz64(row)) << 4); }
+
+#ifdef DC_STAMPS
+// diagnostic build only: per-block s_memtime stamps (never compiled into the shipped library)
+static __device__ unsigned long long* g_stamps;
+extern "C" void dc_debug_set_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#define DC_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DC_STAMP(k) do {} while (0)
+#endif
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BKE = 4 * EPC;                  // channels per 64-byte chunk row
+  constexpr int TM = 8, TN = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Wring = smem + 2 * HALO_XBUF;
+
+  DC_STAMP(0);
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  int tile_m, tile_n;
+  tile_of_block(a, tile_m, tile_n);
+  const int tx = tile_m % g.tiles_x;
+  const int ty = (tile_m / g.tiles_x) % g.tiles_y;
+  const int ng = tile_m / (g.tiles_x * g.tiles_y);
+  const int tw = 1 << g.ltw, th = 1 << g.lth;
+  const int HW = g.H * g.W;
+  const int Ctot = a.C0 + a.C1;
+  const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
+
+  // ---- X loader: lane fetches LDS position p = i*512 + t  -> halo row p>>2, physical chunk p&3 ----
+  constexpr int NXL = HALO_NXL;
+  int prow0[NXL], prow1[NXL];                   // source pixel row (sample*H*W + y*W + x) per source, -1 = zero page
+  const int xl = (t & 3) ^ swz64(t >> 2);       // logical chunk this lane fetches: row = (i*512+t)>>2, and i*128 == 0 mod 16
+#pragma unroll
+  for (int i = 0; i < NXL; ++i) {
+    const int hr = (i * 512 + t) >> 2;
+    prow0[i] = -1; prow1[i] = -1;
+    if (i < g.nxl && hr < g.HR) {
+      const int img = hr / g.hp, r = hr - img * g.hp;
+      const int hy = r / g.hw, hx = r - hy * g.hw;
+      const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
+      const int n = (ng << g.lni) + img;
+      if (n < g.n_img && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
+        const int pix = iy * g.W + ix;
+        prow0[i] = (a.map0 ? a.map0[n] : n) * HW + pix;
+        if (a.src1) prow1[i] = (a.map1 ? a.map1[n] : n) * HW + pix;
+      }
+    }
+    asm volatile("" ::"v"(prow0[i]), "v"(prow1[i]));   // consume the map loads before the LDS-DMA loop
+  }
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (t & 3) * 16;
+
+  auto issue_x = [&](int cc) {
+    const bool s1 = cc >= c0chunks;
+    const T* src = reinterpret_cast<const T*>(s1 ? a.src1 : a.src0);
+    const int ld = s1 ? a.ld1 : a.ld0;
+    const int coff = (s1 ? cc - c0chunks : cc) * BKE + xl * EPC;
+    char* xs = smem + (cc & 1) * HALO_XBUF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      if (i < g.nxl) {
+        const int pr = s1 ? prow1[i] : prow0[i];
+        const size_t e = (size_t)(pr < 0 ? 0 : pr) * ld + coff;
+        const char* gp = pr < 0 ? zero : reinterpret_cast<const char*>(src + e);
+        __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * 8192), 16, 0, 0);
+      }
+    }
+  };
+  // ---- W loader: 128 couts x 64 B per (chunk, tap): position t -> row t>>2, phys chunk t&3 ----
+  const T* wrow = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128 + (t >> 2)) * a.Ktot + xl * EPC;
+  auto issue_w = [&](int s) {                       // s = cc*9 + tap
+    const int cc = s / 9, tap = s - cc * 9;
+    const char* gp = reinterpret_cast<const char*>(wrow + (size_t)tap * Ctot + (size_t)cc * BKE);
+    __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(Wring + (s & 3) * HALO_WST + wave * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment row bases: output pixel p = wm*128 + j*16 + lr -> top-left halo row of its 3x3 window ----
+  int hbase[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int p = wm * 128 + j * 16 + lr;
+    const int img = p >> (g.ltw + g.lth), py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
+    hbase[j] = img * g.hp + py * g.hw + px;
+  }
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int NS = nchunks * 9;
+  DC_STAMP(1);
+  issue_x(0);
+  issue_w(0);
+  issue_w(1);
+  issue_w(2);                                        // NS >= 9 always
+  int tap = 0, cc = 0;
+  for (int s = 0; s < NS; ++s) {
+    // W(s) (and X(cc) when tap == 0) must have landed; younger ops that may stay in flight:
+    // W(s+1), W(s+2) and, for tap in {1,2,3}, the nxl loads of X(cc+1) issued at tap 0.
+    const int rem = NS - 1 - s;
+    if (rem >= 2) {
+      const bool xfly = (tap >= 1 && tap <= 3) && (cc + 1 < nchunks);
+      if (!xfly) wait_vmcnt<2>();
+      else if (g.nxl == 5) wait_vmcnt<7>();
+      else if (g.nxl == 6) wait_vmcnt<8>();
+      else wait_vmcnt<2>();
+    } else if (rem == 1) wait_vmcnt<1>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + 3 < NS) issue_w(s + 3);
+    if (tap == 0 && cc + 1 < nchunks) issue_x(cc + 1);
+
+    const char* Xb = smem + (cc & 1) * HALO_XBUF;
+    const char* Wst = Wring + (s & 3) * HALO_WST;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int tapoff = ky * g.hw + kx;
+    chunk16 xf[TM], wf[TN];
+    // W fragments first, then X; MFMAs in j-major order so the first ones need only wf[*] + xf[0] and the
+    // counted lgkmcnt waits let the matrix pipe start while the later X fragments are still arriving
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + lds64_off(wn * 64 + i * 16 + lr, lq));
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + lds64_off(hbase[j] + tapoff, lq));
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    if (++tap == 9) { tap = 0; ++cc; }
+  }
+
+  DC_STAMP(2);
+  // ---- epilogue: two half passes (256 rows each) through an fp32 LDS tile (igemm_epilogue.h) ----
+  float* otile = reinterpret_cast<float*>(smem);
+  int samp[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int n = (ng << g.lni) + ((wm * 128 + j * 16 + lr) >> (g.ltw + g.lth));
+    samp[j] = n < g.n_img ? n : 0;
+  }
+  for (int half = 0; half < 2; ++half) {
+    __builtin_amdgcn_s_barrier();
+    DC_STAMP(3 + 2 * half);
+    if ((wm >> 1) == half) epi_stage<TM, TN>(a, acc, otile, HALO_OLD, (wm & 1) * 128, wn * 64, tile_n * 128 + wn * 64, samp, lr, lq);
+    __syncthreads();
+    DC_STAMP(4 + 2 * half);
+    epi_store<2>(a, otile, HALO_OLD, 256, 128, tile_n * 128, a.Cout, [&](int rloc, size_t& orow, size_t& rrow) {
+      const int p = half * 256 + rloc;
+      const int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
+      if (n >= g.n_img) return false;
+      const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
+      const int rem = (ty * th + py) * g.W + tx * tw + px;
+      orow = (size_t)n * HW + rem;
+      rrow = (size_t)(a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
+      return true;
+    });
+  }
+  DC_STAMP(7);
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// true when the halo kernel can take this problem (3x3 stride 1, pow-2 extents >= 8, no GEGLU)
+bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
+  if (a.taps != 9 || a.stride != 1 || a.upsample || a.act == DC_ACT_GEGLU) return false;
+  const int H = a.Hin, W = a.Win;
+  if (H < 16 || W < 16 || (H & (H - 1)) || (W & (W - 1))) return false;   // 8x8 and smaller stay on igemm_pipe (tiny, weight-bound)
+  if ((long long)a.M >= (1LL << 31)) return false;
+  const int bke = 64 / dc_dtype_size(dtype);
+  if (a.C0 % bke || a.C1 % bke) return false;
+  return true;
+}
+
+template <typename T>
+static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s) {
+  static bool attr_done = false;
+  auto kern = conv3_halo_kernel<T>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+    attr_done = true;
+  }
+  IgemmArgs a = a0;
+  HaloGeom g;
+  g.H = a.Hin; g.W = a.Win; g.n_img = n_img;
+  const int tw = g.W < 32 ? g.W : 32;
+  int th = 512 / tw; if (th > g.H) th = g.H;
+  const int ni = 512 / (tw * th);
+  g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
+  g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
+  g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
+  g.nxl = (g.HR * 4 + 511) / 512;
+  if (g.HR > HALO_XROWS_MAX || g.nxl > HALO_NXL) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
+  a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
+  const long long nblk = (long long)a.tiles_m * a.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), HALO_LDS, s, a, g);
+  return dc_check_launch("dc_igemm(conv3_halo)");
+}
+
+int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s) {
+  if (dtype == DC_BF16) return launch_halo<__bf16>(a, n_img, s);
+  if (dtype == DC_F16) return launch_halo<_Float16>(a, n_img, s);
+  return launch_halo<float>(a, n_img, s);
+}

@@ -213,6 +213,8 @@ extern "C" int dc_igemm(const dc_igemm_params* p, dc_stream stream) {
   // tile_n 128: the LDS-DMA pipelined 256x128 kernel (igemm_pipe.hip).  DCAMD_IGEMM_V1=1 selects the
   // register-staged 128x128 kernel instead (A/B measurements; same results bit for bit).
   static const bool use_v1 = getenv("DCAMD_IGEMM_V1") != nullptr;
+  static const bool no_halo = getenv("DCAMD_NO_HALO") != nullptr;
+  if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) return dc_conv3_halo_launch(a, p->dtype, p->n_img, s);
   if (bn == 128 && !use_v1) return dc_igemm_launch_pipe(a, p->dtype, s);
   if (bn == 128) {
     if (p->dtype == DC_BF16) return launch<__bf16, 128, 128, 2, 2>(a, s);

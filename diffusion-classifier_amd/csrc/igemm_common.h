@@ -128,3 +128,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 
 // defined in igemm_pipe.hip; returns DC_ERR_UNSUPPORTED-free status (always handles tile_n == 128)
 int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s);
+// conv3_halo.hip
+bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype);
+int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);

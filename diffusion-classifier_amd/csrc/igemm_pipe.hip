@@ -15,7 +15,7 @@
 //                  s_barrier              everybody's have, and everybody finished compute(ks-1)
 //                  issue g[ks+2]          into the stage compute(ks-1) has just released
 //                  compute(ks)            16 ds_read_b128 + 32 MFMA 16x16x32 per wave
-#include "igemm_common.h"
+#include "igemm_epilogue.h"
 
 __device__ chunk16 g_zero_page[16];
 
@@ -120,134 +120,38 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
       const int c = sub * 4 + lq;
       chunk16 xf[TM], wf[TN];
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
-#pragma unroll
       for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wsm + lds_off(wn * 64 + i * 16 + lr, c));
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
     }
   }
-  // ---- epilogue, staged through LDS so that HBM sees whole 16-B chunks of whole rows ----
-  // phase 1 (registers -> LDS, fp32): bias, per-sample row vector, activation, gate.  A lane holds 4
-  // consecutive couts of one pixel per 16x16 tile; rows are padded by 16 B so the 8-lane write groups of
-  // ds_write_b128 fall on distinct banks.  phase 2 (LDS -> HBM): 16 consecutive lanes cover one output
-  // row; residual is read, and the result written, as one 16-byte access per 8 (16-bit) or 4 (f32) couts.
+  // ---- epilogue, staged through LDS so that HBM sees whole 16-byte chunks of whole rows (igemm_epilogue.h) ----
   __builtin_amdgcn_s_barrier();                      // every wave is done reading the operand stages
-  constexpr int OLD = BN + 4;                        // padded row, in floats
+  constexpr int OLD = BN + 4;                        // staging row in floats, +16 B so ds_write_b128 groups spread over banks
   float* otile = reinterpret_cast<float*>(smem);
   const bool geglu = a.act == DC_ACT_GEGLU;
   const int cout_out = geglu ? (a.Cout >> 1) : a.Cout;
-  const int tcols = geglu ? BN / 2 : BN;             // output columns of this tile
-  const int col0 = tile_n * tcols;
-  {
-    const int n0 = tile_n * BN + wn * 64;            // first packed cout of the wave
+  const int tcols = geglu ? BN / 2 : BN;
+  int samp[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int rloc = wm * 64 + j * 16 + lr;
-      const int m = tile_m * BM + rloc;
-      const int mm = m < a.M ? m : 0;
-      const int n = mm / HWo;
-      const float* rv = a.rowvec ? a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[n] : n) * a.rowvec_ld : nullptr;
-      const float* gt = a.gate ? a.gate + (size_t)(a.gate_map ? a.gate_map[n] : n) * a.gate_ld : nullptr;
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int pc = n0 + i * 16 + lq * 4;
-        float v[4];
-        int lc;                                      // column inside the tile
-        if (geglu) {
-          if (i & 1) continue;
-          lc = ((wn * 64 + i * 16) >> 1) + lq * 4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float val = acc[i][j][r], g = acc[(i + 1) % TN][j][r];
-            if (a.bias) { val += a.bias[pc + r]; g += a.bias[pc + 16 + r]; }
-            v[r] = val * gelu_erf_f(g);
-          }
-        } else {
-          lc = wn * 64 + i * 16 + lq * 4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x = acc[i][j][r];
-            const int c = pc + r;
-            if (c < cout_out) {
-              if (a.bias) x += a.bias[c];
-              if (rv) x += rv[c];
-              if (a.act == DC_ACT_SILU) x = silu_f(x);
-              else if (a.act == DC_ACT_GELU_TANH) x = gelu_tanh_f(x);
-              if (gt) x *= gt[c];
-            }
-            v[r] = x;
-          }
-        }
-        *reinterpret_cast<f32x4*>(otile + rloc * OLD + lc) = f32x4{v[0], v[1], v[2], v[3]};
-      }
-    }
+  for (int j = 0; j < TM; ++j) {
+    const int m = tile_m * BM + wm * 64 + j * 16 + lr;
+    samp[j] = (m < a.M ? m : 0) / HWo;
   }
+  epi_stage<TM, TN>(a, acc, otile, OLD, wm * 64, wn * 64, tile_n * BN + wn * 64, samp, lr, lq);
   __syncthreads();
-  {
-    const int es_out = a.out_dtype == DC_F32 ? 4 : 8;          // couts per 16-byte output chunk
-    const int cpr = tcols / es_out;                            // chunks per tile row
-    const bool vec_ok = (cout_out % es_out == 0) && (a.out_ld % es_out == 0) &&
-                        (!a.residual || ((a.res_ld % 8 == 0) && a.res_dtype != DC_F32) || ((a.res_ld % 4 == 0) && a.res_dtype == DC_F32));
-    for (int idx = t; idx < BM * cpr; idx += 512) {
-      const int rloc = idx / cpr, ch = idx - rloc * cpr;
-      const int m = tile_m * BM + rloc;
-      const int c = col0 + ch * es_out;
-      if (m >= a.M || c >= cout_out) continue;
-      const float* src = otile + rloc * OLD + ch * es_out;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
-      f32x4 hi = {0.f, 0.f, 0.f, 0.f};
-      if (es_out == 8) hi = *reinterpret_cast<const f32x4*>(src + 4);
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      size_t rrow = 0;
-      if (a.residual) {
-        const int n = m / HWo;
-        rrow = (a.res_map ? (size_t)a.res_map[n] * HWo + (m - n * HWo) : (size_t)m) * a.res_ld + c;
-      }
-      const size_t o = (size_t)m * a.out_ld + c;
-      if (vec_ok) {
-        if (a.residual) {
-          if (a.res_dtype == DC_F32) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-              if (h * 4 < es_out) {
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.residual) + rrow + h * 4);
-                v[h * 4] += r4[0]; v[h * 4 + 1] += r4[1]; v[h * 4 + 2] += r4[2]; v[h * 4 + 3] += r4[3];
-              }
-          } else {
-            // 16-bit residual: es_out == 8 reads 16 B, es_out == 4 (f32 out) reads 8 B
-            if (es_out == 8) {
-              const chunk16 rc = *reinterpret_cast<const chunk16*>(reinterpret_cast<const char*>(a.residual) + rrow * 2);
-              float rf[8];
-              if (a.res_dtype == DC_BF16) chunk_to_f<__bf16>(rc, rf); else chunk_to_f<_Float16>(rc, rf);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rf[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += load_as(a.residual, rrow + e, a.res_dtype);
-            }
-          }
-        }
-        if (a.out_dtype == DC_F32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = f32x4{v[0], v[1], v[2], v[3]};
-        } else if (a.out_dtype == DC_BF16) {
-          *reinterpret_cast<chunk16*>(reinterpret_cast<__bf16*>(a.out) + o) = f_to_chunk<__bf16>(v);
-        } else {
-          *reinterpret_cast<chunk16*>(reinterpret_cast<_Float16*>(a.out) + o) = f_to_chunk<_Float16>(v);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < es_out && c + e < cout_out) {
-            float x = v[e];
-            if (a.residual) x += load_as(a.residual, rrow + e, a.res_dtype);
-            store_as(a.out, o + e, a.out_dtype, x);
-          }
-      }
-    }
-  }
+  epi_store(a, otile, OLD, BM, tcols, tile_n * tcols, cout_out, [&](int rloc, size_t& orow, size_t& rrow) {
+    const int m = tile_m * BM + rloc;
+    if (m >= a.M) return false;
+    orow = (size_t)m;
+    rrow = (size_t)m;
+    if (a.residual && a.res_map) { const int n = m / HWo; rrow = (size_t)a.res_map[n] * HWo + (m - n * HWo); }
+    return true;
+  });
 }
 
 template <typename T>

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of dc_igemm on the shapes that dominate the cfg2 scoring step (developer tool;
+also the target of the rocprofv3 --pmc passes whose summaries are committed under profiles/).
+  python tools/bench_igemm.py [--reps 20] [--dtype bf16] [--shapes name,...]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diffusion_classifier_amd as dca  # noqa: E402
+from diffusion_classifier_amd import _lib as L  # noqa: E402
+from diffusion_classifier_amd import engine as E  # noqa: E402
+
+# name: (n_img, H, W, Cin, Cout, taps, residual)
+SHAPES = {
+    "c32_128_128": (1020, 32, 32, 128, 128, 9, True),
+    "c32_256_128": (1020, 32, 32, 256, 128, 9, False),
+    "c16_256_128": (1020, 16, 16, 256, 128, 9, False),
+    "c16_128_128": (1020, 16, 16, 128, 128, 9, True),
+    "c8_512_256": (1020, 8, 8, 512, 256, 9, False),
+    "c4_1024_512": (1020, 4, 4, 1024, 512, 9, False),
+    "p32_256_128": (1020, 32, 32, 256, 128, 1, False),
+    "g64_256_2048": (1020, 64, 1, 256, 2048, 1, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--shapes", default=",".join(SHAPES))
+    args = ap.parse_args()
+    dt = E.DT[args.dtype]
+    td = E.TORCH_DT[dt]
+    lib = L.require_gpu()
+    dev = "cuda:0"
+    for name in args.shapes.split(","):
+        n, H, W, Ci, Co, taps, res = SHAPES[name]
+        x = torch.randn(n, H, W, Ci, device=dev).to(td)
+        w = torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5) if taps == 9 else torch.randn(Co, Ci) / Ci ** 0.5
+        Wp = E.pack_conv3x3(w, dt, dev) if taps == 9 else E.pack_matrix(w, dt, dev)
+        b = torch.randn(Co, device=dev)
+        r = torch.randn(n, H, W, Co, device=dev).to(td) if res else None
+        out = torch.empty(n, H, W, Co, device=dev, dtype=td)
+        p = L.IgemmParams(dtype=dt, taps=taps, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W,
+                          src0=x.data_ptr(), C0=Ci, W=Wp.data_ptr(), Cout=Co, tile_n=128, bias=b.data_ptr(),
+                          residual=r.data_ptr() if res else None, res_dtype=dt, res_ld=Co,
+                          out=out.data_ptr(), out_dtype=dt, out_ld=Co)
+        for _ in range(3):
+            L.check(lib.dc_igemm(p, L.stream_ptr()))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            L.check(lib.dc_igemm(p, L.stream_ptr()))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        fl = 2.0 * n * H * W * Ci * taps * Co
+        print(f"{name:14s} M={n * H * W:8d} N={Co:5d} K={Ci * taps:5d}  {ms:8.4f} ms  {fl / ms / 1e9:7.1f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    main()
