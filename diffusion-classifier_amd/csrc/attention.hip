@@ -8,6 +8,7 @@
 // keeps everything on-chip and exact in fp32: K and V of one (sample, head) live in LDS as f32,
 // each query is owned by d/16 adjacent lanes holding a 16-wide slice of q and of the output,
 // scores are reduced across those lanes with xor-shuffles, softmax is online (running max / sum).
+#include <stdlib.h>
 #include "common.h"
 
 struct AttnArgs {
@@ -65,11 +66,17 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs a) {
   }
 }
 
+// attention_mfma.hip: matrix-core kernel for 16-bit dtypes, L % 16 == 0, d % 32 == 0
+bool dc_attn_mfma_applicable(int dtype, int L, int d);
+int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s);
+
 extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   DC_REQUIRE(p && p->q && p->k && p->v && p->out, DC_ERR_ARG, "dc_attention: null pointer");
   DC_REQUIRE(p->d == 16 || p->d == 32 || p->d == 64 || p->d == 128, DC_ERR_SHAPE, "dc_attention: head dim %d (16/32/64/128)", p->d);
   DC_REQUIRE(p->n > 0 && p->L > 0 && p->heads > 0, DC_ERR_SHAPE, "dc_attention: n/L/heads");
   DC_REQUIRE(p->ld_qkv >= p->heads * p->d && p->ld_out >= p->heads * p->d, DC_ERR_SHAPE, "dc_attention: ld");
+  static const bool no_mfma = getenv("DCAMD_ATTN_VALU") != nullptr;
+  if (!no_mfma && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
   const size_t lds = (size_t)2 * p->L * p->d * sizeof(float);
   DC_REQUIRE(lds <= 160 * 1024, DC_ERR_UNSUPPORTED,
              "dc_attention: L=%d d=%d needs %zu B of LDS (>160 KiB); long-sequence path not built yet", p->L, p->d, lds);

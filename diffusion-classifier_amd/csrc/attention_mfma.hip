@@ -1,0 +1,163 @@
+// attention_mfma.hip — self-attention on the matrix cores for the UNet token counts (16-bit dtypes).
+//
+// One 4-wave workgroup per group of (sample, head) pairs: 1 pair when L >= 64, 2 when L == 32,
+// 4 when L == 16, so every wave owns whole 16-query tiles.  K [L][d] and V^T [d][L] of a pair
+// live in LDS (V is transposed while it is staged, so both MFMA operands are k-contiguous);
+// Q fragments come straight from global memory.  Per 16-query tile:
+//   S = Q K^T   (L/16 x d/32 MFMA 16x16x32, fp32 accumulate; lane holds 4 queries x 1 key per tile)
+//   softmax over keys in fp32 registers (max/sum: across tiles, then xor-shuffles over the 16 lanes
+//   that share a query), P -> 16-bit into a per-wave LDS strip in [query][key] order
+//   O = P V     (d/16 x L/32 MFMA), scaled by 1/rowsum, stored as 16-bit.
+// The fp32 kernel of attention.hip stays the path for f32 (exact) and for shapes outside
+// L % 16 == 0, d % 32 == 0.
+#include "igemm_common.h"
+
+struct AttnMArgs {
+  const void* q; const void* k; const void* v; void* out;
+  int n, L, heads, d, ld_qkv, ld_out, G, Lp; float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int L = a.L, d = a.d, Lp = a.Lp, G = a.G;
+  const int KS = d + 8, VS = Lp + 8, PS = Lp + 8;                // row strides in elements (+16 B pad)
+  const int pair_bytes = (L * KS + d * VS) * 2;
+  const int wpp = 4 / G;                                        // waves per pair
+  const int g = wave / wpp, wl = wave - g * wpp;
+  const long long pair = (long long)blockIdx.x * G + g;
+  const long long npairs = (long long)a.n * a.heads;
+  const bool pair_ok = pair < npairs;
+  const int n = (int)((pair_ok ? pair : 0) / a.heads), h = (int)((pair_ok ? pair : 0) % a.heads);
+  T* Ks = reinterpret_cast<T*>(smem + g * pair_bytes);
+  T* Vt = Ks + L * KS;
+  T* Pw = reinterpret_cast<T*>(smem + G * pair_bytes) + wave * 16 * PS;
+  const T* qg = reinterpret_cast<const T*>(a.q) + (size_t)n * L * a.ld_qkv + h * d;
+  const T* kg = reinterpret_cast<const T*>(a.k) + (size_t)n * L * a.ld_qkv + h * d;
+  const T* vg = reinterpret_cast<const T*>(a.v) + (size_t)n * L * a.ld_qkv + h * d;
+
+  // ---- stage K (row-major) and V^T into LDS, cooperatively by the waves of the pair ----
+  const int tl = wl * 64 + lane, nth = wpp * 64;
+  const int cpr = d / 8;                                        // 16-byte chunks per K/V row
+  for (int idx = tl; idx < L * cpr; idx += nth) {
+    const int r = idx / cpr, c = idx - r * cpr;
+    const chunk16 kc = *reinterpret_cast<const chunk16*>(kg + (size_t)r * a.ld_qkv + c * 8);
+    *reinterpret_cast<chunk16*>(Ks + r * KS + c * 8) = kc;
+    const chunk16 vc = *reinterpret_cast<const chunk16*>(vg + (size_t)r * a.ld_qkv + c * 8);
+    const typename Elem<T>::vec ve = __builtin_bit_cast(typename Elem<T>::vec, vc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VS + r] = ve[e];
+  }
+  for (int idx = tl; idx < d * (Lp - L); idx += nth) {          // zero the padded keys (L == 16 -> Lp == 32)
+    const int r = idx / (Lp - L), c = L + idx - r * (Lp - L);
+    Vt[r * VS + c] = Elem<T>::from_f(0.f);
+  }
+  __syncthreads();
+  if (!pair_ok) return;
+
+  const int ktiles = L / 16, kblocks = d / 32;
+  for (int qt = wl; qt < ktiles; qt += wpp) {
+    const int q0 = qt * 16;
+    chunk16 qf[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      if (kb < kblocks) qf[kb] = *reinterpret_cast<const chunk16*>(qg + (size_t)(q0 + lr) * a.ld_qkv + kb * 32 + lq * 8);
+    // S tiles: queries q0 + lq*4 + r, key kt*16 + lr
+    f32x4 S[16];
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      if (kt < ktiles) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          if (kb < kblocks) {
+            const chunk16 kf = *reinterpret_cast<const chunk16*>(Ks + (kt * 16 + lr) * KS + kb * 32 + lq * 8);
+            acc = Mma<T>::run(qf[kb], kf, acc);
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[r] *= a.scale; m[r] = fmaxf(m[r], acc[r]); }
+        S[kt] = acc;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], o, 64));
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      if (kt < ktiles) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = expf(S[kt][r] - m[r]);
+          sum[r] += p;
+          Pw[(lq * 4 + r) * PS + kt * 16 + lr] = Elem<T>::from_f(p);
+        }
+      }
+    }
+    if (Lp != L) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pw[(lq * 4 + r) * PS + L + lr] = Elem<T>::from_f(0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sum[r] += __shfl_xor(sum[r], o, 64);
+    __builtin_amdgcn_wave_barrier();     // P strip is private to this wave: LDS executes its ops in issue order
+    // O tiles: queries q0 + lq*4 + r, channel dt*16 + lr
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      if (dt * 16 < d) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kb2 = 0; kb2 < Lp / 32; ++kb2) {
+          const chunk16 pf = *reinterpret_cast<const chunk16*>(Pw + lr * PS + kb2 * 32 + lq * 8);
+          const chunk16 vf = *reinterpret_cast<const chunk16*>(Vt + (dt * 16 + lr) * VS + kb2 * 32 + lq * 8);
+          acc = Mma<T>::run(pf, vf, acc);
+        }
+        T* op = reinterpret_cast<T*>(a.out) + ((size_t)n * L + q0 + lq * 4) * a.ld_out + h * d + dt * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[(size_t)r * a.ld_out] = Elem<T>::from_f(acc[r] / sum[r]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+bool dc_attn_mfma_applicable(int dtype, int L, int d) {
+  if (dtype == DC_F32) return false;
+  if (L % 16 || L > 256 || d % 32 || d > 128) return false;
+  const int G = L >= 64 ? 1 : (L == 32 ? 2 : (L == 16 ? 4 : 0));
+  if (!G) return false;
+  const int Lp = (L + 31) / 32 * 32;
+  const size_t lds = (size_t)G * (L * (d + 8) + d * (Lp + 8)) * 2 + (size_t)4 * 16 * (Lp + 8) * 2;
+  return lds <= 160 * 1024;
+}
+
+int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s) {
+  AttnMArgs a;
+  a.q = p->q; a.k = p->k; a.v = p->v; a.out = p->out; a.n = p->n; a.L = p->L; a.heads = p->heads; a.d = p->d;
+  a.ld_qkv = p->ld_qkv; a.ld_out = p->ld_out; a.scale = p->scale;
+  a.G = p->L >= 64 ? 1 : (p->L == 32 ? 2 : 4);
+  a.Lp = (p->L + 31) / 32 * 32;
+  const size_t lds = (size_t)a.G * (a.L * (a.d + 8) + a.d * (a.Lp + 8)) * 2 + (size_t)4 * 16 * (a.Lp + 8) * 2;
+  const long long npairs = (long long)p->n * p->heads;
+  const long long nb = (npairs + a.G - 1) / a.G;
+  if (nb >= (1LL << 31)) { dc_set_error("dc_attention: grid too large"); return DC_ERR_SHAPE; }
+  if (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v) & 15 || (p->ld_qkv % 8)) {
+    dc_set_error("dc_attention: q/k/v must be 16-byte aligned with ld %% 8 == 0");
+    return DC_ERR_ALIGN;
+  }
+  static bool done_b = false, done_h = false;
+  if (p->dtype == DC_BF16) {
+    if (!done_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_b = true; }
+    hipLaunchKernelGGL((attn_mfma_kernel<__bf16>), dim3((unsigned)nb), dim3(256), lds, s, a);
+  } else {
+    if (!done_h) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_h = true; }
+    hipLaunchKernelGGL((attn_mfma_kernel<_Float16>), dim3((unsigned)nb), dim3(256), lds, s, a);
+  }
+  return dc_check_launch("dc_attention(mfma)");
+}

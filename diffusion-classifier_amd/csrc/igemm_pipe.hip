@@ -100,6 +100,9 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
     if (++icc == a.cpt) { icc = 0; ++itap; }
   };
 
+  // number of 16-row pixel tiles of this wave that contain real rows
+  const int rows_left = a.M - (tile_m * BM + wm * 64);
+  const int jmax = __builtin_amdgcn_readfirstlane(rows_left <= 0 ? 0 : (rows_left >= 64 ? 4 : (rows_left + 15) >> 4));
   f32x4 acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -121,12 +124,22 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
       chunk16 xf[TM], wf[TN];
 #pragma unroll
       for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wsm + lds_off(wn * 64 + i * 16 + lr, c));
+      if (jmax == TM) {           // the hot path: every pixel tile of the wave is real
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+          for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+      } else {                    // small-M side-path GEMMs: pixel tiles past M cost nothing (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          if (j < jmax) {
+            const chunk16 x1 = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
+#pragma unroll
+            for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], x1, acc[i][j]);
+          }
+      }
     }
   }
   // ---- epilogue, staged through LDS so that HBM sees whole 16-byte chunks of whole rows (igemm_epilogue.h) ----

@@ -310,6 +310,7 @@ class _HipRunner:
         score["x"].copy_(self.x_dev)
         if dc.encoder is not None:
             plan.ctx.copy_(dc.encoder.weight[:ncls].detach().to(dev, torch.float32))
+        plan.run_ctx()                                   # per-class vectors: once per stage, not per micro-batch
         n_mb = -(-len(pairs) // n_bj)
         host = torch.zeros((n_mb, sp["words"]), dtype=torch.int32).pin_memory()
         dump = BS * ncls * T

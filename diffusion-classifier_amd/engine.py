@@ -497,15 +497,21 @@ class UNetPlan:
         te = pb.igemm("temb.l2", te, pb.const(P["time_embedding.linear_2.w"]), 4 * C0,
                       bias=pb.const(P["time_embedding.linear_2.b"]), act=L.ACT_SILU)   # = SiLU(temb)
         tproj = pb.igemm("tproj", te, pb.const(P["tproj.w"]), weights.tproj_total, bias=pb.const(P["tproj.b"]))
-        hp = pb.igemm("ctx.hid_proj", ctx, pb.const(P["encoder_hid_proj.w"]), cfg.cross_attention_dim,
-                      bias=pb.const(P["encoder_hid_proj.b"]))
-        vall = pb.igemm("ctx.to_v", hp, pb.const(P["attn2v.w"]), weights.cv_total)
-        cvec = {}
+        # class-token vectors: their own small plan (run_ctx), executed once per classify call / forward and
+        # NOT once per micro-batch: they depend only on the weights and on `ctx`
+        pc = self.ctx_pb = PlanBuilder(dev, 1, 1, n_ctx)
+        cctx = pc.external("ctx", self.ctx, "ctx", 1, 1, cfg.encoder_hid_dim, L.DC_F32)
+        hp = pc.igemm("ctx.hid_proj", cctx, pc.const(P["encoder_hid_proj.w"]), cfg.cross_attention_dim,
+                      bias=pc.const(P["encoder_hid_proj.b"]))
+        vall = pc.igemm("ctx.to_v", hp, pc.const(P["attn2v.w"]), weights.cv_total)
+        cv_t = {}
         for k in weights.attns:
             tbk = k + ".transformer_blocks.0"
             Ck = P[k + ".norm.g"].shape[0]
-            cvec[k] = pb.igemm(k + ".cvec", vall.view(weights.cv_off[k], Ck), pb.const(P[tbk + ".attn2.to_out.0.w"]), Ck,
-                               bias=pb.const(P[tbk + ".attn2.to_out.0.b"]))
+            cv_t[k] = pc.igemm(k + ".cvec", vall.view(weights.cv_off[k], Ck), pc.const(P[tbk + ".attn2.to_out.0.w"]), Ck,
+                               bias=pc.const(P[tbk + ".attn2.to_out.0.b"]))
+        pc.finalize(keep_alive=list(cv_t.values()))
+        cvec = {k: pb.external(k + ".cvec", pc.tensor_view(t).view(n_ctx, -1), "ctx", 1, 1, t.C, L.DC_F32) for k, t in cv_t.items()}
 
         def resnet(key, x0, x1=None):
             Cout = P[key + ".conv1.b"].shape[0]
@@ -583,6 +589,10 @@ class UNetPlan:
 
     def run(self):
         self.pb.run()
+
+    def run_ctx(self):
+        """Refresh the per-class cross-attention vectors from `self.ctx` (call after changing ctx / weights)."""
+        self.ctx_pb.run()
 
     def pred_view(self):
         return self.pb.tensor_view(self.pred)

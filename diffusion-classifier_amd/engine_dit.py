@@ -130,6 +130,9 @@ class DiTPlan:
     def run(self):
         self.pb.run()
 
+    def run_ctx(self):
+        pass   # class conditioning is a table row picked inside the plan
+
     def pred_view(self):
         return self.pb.tensor_view(self.pred)
 

@@ -275,6 +275,7 @@ class UNetCondition2D(_HipBackbone):
                             out=plan.a0_buf.data_ptr(), out_dtype=plan.dt, n_bj=N, C=Cin, H=H, W=W,
                             ld=plan.a0_buf.shape[-1], im2col=1)
         L.check(lib.dc_qsample(p, L.stream_ptr()), "dc_qsample")
+        plan.run_ctx()
         plan.run()
         return plan.pred_view().permute(0, 3, 1, 2).contiguous().to(x.dtype)
 
