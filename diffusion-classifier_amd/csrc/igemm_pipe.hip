@@ -15,6 +15,7 @@
 //                  s_barrier              everybody's have, and everybody finished compute(ks-1)
 //                  issue g[ks+2]          into the stage compute(ks-1) has just released
 //                  compute(ks)            16 ds_read_b128 + 32 MFMA 16x16x32 per wave
+#include <stdlib.h>
 #include "igemm_epilogue.h"
 
 __device__ chunk16 g_zero_page[16];
@@ -22,11 +23,20 @@ __device__ chunk16 g_zero_page[16];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BM = 256, S = 3: 8 waves, 144 KiB, one workgroup per CU  — long K loops (3x3 convs, big-K GEMMs)
+// BM = 128, S = 2: 4 waves,  66 KiB, two workgroups per CU — short K loops, where the prologue/epilogue of
+//                  one workgroup must overlap the K loop of the other (K <= 512 spends most of a tile there)
+template <typename T, int BM, int S>
+__global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKE = 8 * EPC;
-  constexpr int BM = 256, BN = 128, S = 3;
+  constexpr int BN = 128;
+  constexpr int NT = BM * 2;                 // threads
+  constexpr int RPI = NT / 8;                // tile rows covered by one LDS-DMA instruction of the workgroup
+  constexpr int WL = BN / RPI;               // W loads per lane per K-step (X loads: BM / RPI == 4)
+  constexpr int LPS = 4 + WL;                // LDS-DMA instructions per lane per K-step
   constexpr int XST = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int TM = 4, TN = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -43,7 +53,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
   const int pad = (a.taps == 9) ? 1 : 0;
   const int Hs = a.upsample ? (a.Hin >> 1) : a.Hin;
   const int Ws = a.upsample ? (a.Win >> 1) : a.Win;
-  const int lrow = t >> 3;                                   // 0..63; loader rows are lrow + 64*i
+  const int lrow = t >> 3;                                   // loader rows are lrow + RPI*i
   const int lchunk = (t & 7) ^ ((t >> 4) & 7);               // logical chunk this lane fetches (same for every i)
 
   // per loader row: 64-bit sample base of each source (map lookups happen HERE, never in the loop),
@@ -51,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
   const T* base0[4]; const T* base1[4]; int iy0[4], ix0[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = tile_m * BM + lrow + 64 * i;
+    const int m = tile_m * BM + lrow + RPI * i;
     const bool vm = m < a.M;
     const int mm = vm ? m : 0;
     const int n = mm / HWo;
@@ -89,13 +99,13 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
       const int off = (sy * Ws + sx) * ld + coff;
       const char* gp = reinterpret_cast<const char*>((s1 ? base1[i] : base0[i]) + off);
       gp = ok ? gp : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
     }
     char* ws = smem + st * STAGE + XST + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const char* gp = reinterpret_cast<const char*>(wbase + (size_t)(64 * i) * a.Ktot + (size_t)ks * BKE);
-      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(ws + i * 8192), 16, 0, 0);
+    for (int i = 0; i < WL; ++i) {
+      const char* gp = reinterpret_cast<const char*>(wbase + (size_t)(RPI * i) * a.Ktot + (size_t)ks * BKE);
+      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(ws + i * (NT * 16)), 16, 0, 0);
     }
     if (++icc == a.cpt) { icc = 0; ++itap; }
   };
@@ -110,12 +120,12 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   issue(0);
-  if (a.nk > 1) issue(1);
+  if (S == 3 && a.nk > 1) issue(1);
   for (int ks = 0; ks < a.nk; ++ks) {
-    if (ks + 1 < a.nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (S == 3 && ks + 1 < a.nk) wait_vmcnt<LPS>();   // group ks+1 may stay in flight
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (ks + 2 < a.nk) issue(ks + 2);
+    if (ks + S - 1 < a.nk) issue(ks + S - 1);
     const char* Xs = smem + (ks % S) * STAGE;
     const char* Wsm = Xs + XST;
 #pragma unroll
@@ -167,25 +177,32 @@ __global__ __launch_bounds__(512, 2) void igemm_pipe_kernel(const IgemmArgs a) {
   });
 }
 
-template <typename T>
+template <typename T, int BM, int S>
 static int launch_pipe(const IgemmArgs& a0, hipStream_t s) {
-  constexpr int lds = 3 * (256 + 128) * 128;   // 144 KiB of the CU's 160 KiB
+  constexpr int lds_main = S * (BM + 128) * 128, lds_epi = BM * (128 + 4) * 4;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;   // 144 KiB (BM 256, S 3) / 66 KiB (BM 128, S 2)
   static bool attr_done = false;
-  auto kern = igemm_pipe_kernel<T>;
+  auto kern = igemm_pipe_kernel<T, BM, S>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   IgemmArgs a = a0;
-  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_m = (a.M + BM - 1) / BM;
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("dc_igemm: bad grid %lld", nblk); return DC_ERR_SHAPE; }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BM * 2), lds, s, a);
   return dc_check_launch("dc_igemm(pipe)");
 }
 
 int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s) {
-  if (dtype == DC_BF16) return launch_pipe<__bf16>(a, s);
-  if (dtype == DC_F16) return launch_pipe<_Float16>(a, s);
-  return launch_pipe<float>(a, s);
+  static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
+  if (a.nk <= light_nk) {
+    if (dtype == DC_BF16) return launch_pipe<__bf16, 128, 2>(a, s);
+    if (dtype == DC_F16) return launch_pipe<_Float16, 128, 2>(a, s);
+    return launch_pipe<float, 128, 2>(a, s);
+  }
+  if (dtype == DC_BF16) return launch_pipe<__bf16, 256, 3>(a, s);
+  if (dtype == DC_F16) return launch_pipe<_Float16, 256, 3>(a, s);
+  return launch_pipe<float, 256, 3>(a, s);
 }
