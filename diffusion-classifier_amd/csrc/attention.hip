@@ -69,6 +69,8 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs a) {
 // attention_mfma.hip: matrix-core kernel for 16-bit dtypes, L % 16 == 0, d % 32 == 0
 bool dc_attn_mfma_applicable(int dtype, int L, int d);
 int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s);
+bool dc_attn_flash_applicable(int dtype, int L, int d);     // long sequences (DiT), online softmax
+int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s);
 
 extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   DC_REQUIRE(p && p->q && p->k && p->v && p->out, DC_ERR_ARG, "dc_attention: null pointer");
@@ -77,7 +79,10 @@ extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   DC_REQUIRE(p->ld_qkv >= p->heads * p->d && p->ld_out >= p->heads * p->d, DC_ERR_SHAPE, "dc_attention: ld");
   static const bool no_mfma = getenv("DCAMD_ATTN_VALU") != nullptr;
   if (!no_mfma && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
+  static const bool force_flash = getenv("DCAMD_ATTN_FLASH") != nullptr;
   const size_t lds = (size_t)2 * p->L * p->d * sizeof(float);
+  if (!no_mfma && (lds > 160 * 1024 || force_flash) && dc_attn_flash_applicable(p->dtype, p->L, p->d))
+    return dc_attn_flash_launch(p, reinterpret_cast<hipStream_t>(stream));
   DC_REQUIRE(lds <= 160 * 1024, DC_ERR_UNSUPPORTED,
              "dc_attention: L=%d d=%d needs %zu B of LDS (>160 KiB); long-sequence path not built yet", p->L, p->d, lds);
   AttnArgs a{p->q, p->k, p->v, p->out, p->n, p->L, p->heads, p->d, p->ld_qkv, p->ld_out, p->scale};

@@ -161,3 +161,164 @@ int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s) {
   }
   return dc_check_launch("dc_attention(mfma)");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Long sequences (DiT: 1024 / 4096 tokens): flash-style forward.  A 4-wave workgroup owns 128 queries
+// of one (sample, head) — 32 per wave, two 16-query MFMA tiles — and walks the keys in blocks of 128:
+// K block [128][d] and V^T block [d][128] are staged in LDS once per block and shared by the four
+// waves; scores, running max / sum and the output accumulators stay in registers (online softmax,
+// fp32); P goes through a per-wave LDS strip to become the A operand of P.V.
+struct FlashArgs {
+  const void* q; const void* k; const void* v; void* out;
+  int n, L, heads, d, ld_qkv, ld_out; float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
+  constexpr int KB = 128;                                     // keys per block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int L = a.L, d = a.d;
+  const int KS = d + 8, VS = KB + 8, PS = KB + 8;
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vt = Ks + KB * KS;
+  T* Pw = Vt + d * VS + wave * 32 * PS;
+  const int qblocks = (L + 127) / 128;
+  int b = blockIdx.x;
+  const int qb = b % qblocks; b /= qblocks;
+  const int h = b % a.heads, n = b / a.heads;
+  const T* qg = reinterpret_cast<const T*>(a.q) + (size_t)n * L * a.ld_qkv + h * d;
+  const T* kg = reinterpret_cast<const T*>(a.k) + (size_t)n * L * a.ld_qkv + h * d;
+  const T* vg = reinterpret_cast<const T*>(a.v) + (size_t)n * L * a.ld_qkv + h * d;
+  const int kblocks = d / 32, dtiles = d / 16;
+  const int q0 = qb * 128 + wave * 32;                        // first query of this wave
+
+  chunk16 qf[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      if (kb < kblocks) {
+        const int qi = q0 + qt * 16 + lr;
+        qf[qt][kb] = *reinterpret_cast<const chunk16*>(qg + (size_t)(qi < L ? qi : L - 1) * a.ld_qkv + kb * 32 + lq * 8);
+      }
+  f32x4 O[2][8];
+  float m[2][4], l[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) O[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[qt][r] = -INFINITY; l[qt][r] = 0.f; }
+  }
+  const int cpr = d / 8;
+  for (int k0 = 0; k0 < L; k0 += KB) {
+    __syncthreads();                                          // previous block fully consumed
+    for (int idx = t; idx < KB * cpr; idx += 256) {
+      const int r = idx / cpr, c = idx - r * cpr;
+      const int key = k0 + r;
+      chunk16 kc = {0u, 0u, 0u, 0u}, vc = {0u, 0u, 0u, 0u};
+      if (key < L) {
+        kc = *reinterpret_cast<const chunk16*>(kg + (size_t)key * a.ld_qkv + c * 8);
+        vc = *reinterpret_cast<const chunk16*>(vg + (size_t)key * a.ld_qkv + c * 8);
+      }
+      *reinterpret_cast<chunk16*>(Ks + r * KS + c * 8) = kc;
+      const typename Elem<T>::vec ve = __builtin_bit_cast(typename Elem<T>::vec, vc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VS + r] = ve[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x4 S[8];
+      float mx[4] = {m[qt][0], m[qt][1], m[qt][2], m[qt][3]};
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          if (kb < kblocks) {
+            const chunk16 kf = *reinterpret_cast<const chunk16*>(Ks + (kt * 16 + lr) * KS + kb * 32 + lq * 8);
+            acc = Mma<T>::run(qf[qt][kb], kf, acc);
+          }
+        const bool kvalid = k0 + kt * 16 + lr < L;             // keys past L never win the max nor add to the sum
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[r] = kvalid ? acc[r] * a.scale : -INFINITY; mx[r] = fmaxf(mx[r], acc[r]); }
+        S[kt] = acc;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+      float corr[4], ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { corr[r] = expf(m[qt][r] - mx[r]); m[qt][r] = mx[r]; }
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = expf(S[kt][r] - mx[r]);
+          ps[r] += p;
+          Pw[(qt * 16 + lq * 4 + r) * PS + kt * 16 + lr] = Elem<T>::from_f(p);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ps[r] += __shfl_xor(ps[r], o, 64);
+        l[qt][r] = l[qt][r] * corr[r] + ps[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+        if (dt < dtiles) {
+          f32x4 acc = O[qt][dt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] *= corr[r];
+#pragma unroll
+          for (int kb2 = 0; kb2 < KB / 32; ++kb2) {
+            const chunk16 pf = *reinterpret_cast<const chunk16*>(Pw + (qt * 16 + lr) * PS + kb2 * 32 + lq * 8);
+            const chunk16 vf = *reinterpret_cast<const chunk16*>(Vt + (dt * 16 + lr) * VS + kb2 * 32 + lq * 8);
+            acc = Mma<T>::run(pf, vf, acc);
+          }
+          O[qt][dt] = acc;
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      if (dt < dtiles) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = q0 + qt * 16 + lq * 4 + r;
+          if (qi < L)
+            reinterpret_cast<T*>(a.out)[((size_t)n * L + qi) * a.ld_out + h * d + dt * 16 + lr] = Elem<T>::from_f(O[qt][dt][r] / l[qt][r]);
+        }
+      }
+}
+
+bool dc_attn_flash_applicable(int dtype, int L, int d) { return dtype != DC_F32 && d % 32 == 0 && d <= 128 && L >= 1; }
+
+int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s) {
+  FlashArgs a{p->q, p->k, p->v, p->out, p->n, p->L, p->heads, p->d, p->ld_qkv, p->ld_out, p->scale};
+  if ((((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v) & 15) || (p->ld_qkv % 8)) {
+    dc_set_error("dc_attention: q/k/v must be 16-byte aligned with ld %% 8 == 0");
+    return DC_ERR_ALIGN;
+  }
+  const size_t lds = ((size_t)128 * (p->d + 8) + (size_t)p->d * 136 + (size_t)4 * 32 * 136) * 2;
+  const long long nb = (long long)p->n * p->heads * ((p->L + 127) / 128);
+  if (nb >= (1LL << 31)) { dc_set_error("dc_attention: grid too large"); return DC_ERR_SHAPE; }
+  static bool done_b = false, done_h = false;
+  if (p->dtype == DC_BF16) {
+    if (!done_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_flash_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_b = true; }
+    hipLaunchKernelGGL((attn_flash_kernel<__bf16>), dim3((unsigned)nb), dim3(256), lds, s, a);
+  } else {
+    if (!done_h) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_flash_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_h = true; }
+    hipLaunchKernelGGL((attn_flash_kernel<_Float16>), dim3((unsigned)nb), dim3(256), lds, s, a);
+  }
+  return dc_check_launch("dc_attention(flash)");
+}

@@ -198,3 +198,35 @@ def test_small_dit_forward_and_classify_f32():
     got_l, got_e = dc.classify(xx.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
     assert ((got_e - ref_e).abs() / ref_e).max().item() < 1e-4
     assert got_l.cpu().tolist() == ref_l.tolist()
+
+
+def test_dit_b4_shaped_blocks_f16_against_lowp_oracle():
+    """BASELINE config-5 geometry (models/chexpert-256-dit-b4.py: 12 heads x 64, patch 4, 12x128x128 DWT input ->
+    1024 tokens) with 2 of the 12 layers: exercises the 1024-token flash attention path in fp16."""
+    kw = dict(dca.chexpert_dit_b4_kwargs(True), num_layers=2, num_embeds_ada_norm=10)
+    torch.manual_seed(21)
+    m = dca.DiT(**kw)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
+    o = oracle.OracleDiT(**kw, lowp=True, lowp_dtype=torch.float16)
+    o.load_state_dict(m.state_dict())
+    N = 2
+    x, lam, lab = torch.randn(N, 12, 128, 128) * 0.5, torch.tensor([2.0, -3.0]), torch.tensor([1, 7])
+    ref = o(x, lam, lab)
+    got = m.to(DEV).set_compute_dtype("f16")(x.to(DEV), lam.to(DEV), lab.to(DEV)).cpu()
+    assert relerr(got, ref) < 5e-3, relerr(got, ref)
+
+
+def test_chexpert_dwt_unet_forward_bf16():
+    """BASELINE config-3 architecture (models/chexpert-256-unet-dwt-healthysick.py), 12x128x128, one forward in bf16
+    against the oracle with the same storage rounding; also checks trunk sharing on a 5-level UNet."""
+    kw = dca.chexpert_dwt_unet_kwargs()
+    m, o = make_pair(kw, seed=22, lowp=True)
+    torch.manual_seed(23)
+    N = 2
+    x, lam, emb = torch.randn(N, 12, 128, 128) * 0.5, torch.tensor([1.5, -2.5]), torch.randn(N, 1, 512)
+    ref = o(x, lam, encoder_hidden_states=emb)
+    got = m.to(DEV).set_compute_dtype("bf16")(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    assert relerr(got, ref) < 2e-2, relerr(got, ref)
