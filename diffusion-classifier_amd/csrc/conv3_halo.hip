@@ -82,7 +82,11 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
   // ---- X loader: lane fetches LDS position p = i*512 + t  -> halo row p>>2, physical chunk p&3 ----
   constexpr int NXL = HALO_NXL;
   int prow0[NXL], prow1[NXL];                   // source pixel row (sample*H*W + y*W + x) per source, -1 = zero page
-  const int xl = (t & 3) ^ swz64(t >> 2);       // logical chunk this lane fetches: row = (i*512+t)>>2, and i*128 == 0 mod 16
+  // X halo image is stored UN-swizzled ([row][4 chunks]): its fragment reads are 2-way bank conflicted, but the read
+  // address of (pixel tile j, tap) becomes one add of a wave-uniform tap offset to a per-lane constant.  (The swizzled
+  // image needed ~10 VALU per read: rocprofv3 counted 4.4 VALU per MFMA and instruction issue at 38 % of wave time.)
+  const int xlx = t & 3;
+  const int xl = (t & 3) ^ swz64(t >> 2);       // W tile keeps the swizzle: logical chunk of row t>>2
 #pragma unroll
   for (int i = 0; i < NXL; ++i) {
     const int hr = (i * 512 + t) >> 2;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
     const bool s1 = cc >= c0chunks;
     const T* src = reinterpret_cast<const T*>(s1 ? a.src1 : a.src0);
     const int ld = s1 ? a.ld1 : a.ld0;
-    const int coff = (s1 ? cc - c0chunks : cc) * BKE + xl * EPC;
+    const int coff = (s1 ? cc - c0chunks : cc) * BKE + xlx * EPC;
     char* xs = smem + (cc & 1) * HALO_XBUF + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
@@ -127,13 +131,15 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
   };
 
   // ---- fragment row bases: output pixel p = wm*128 + j*16 + lr -> top-left halo row of its 3x3 window ----
-  int hbase[TM];
+  int xoff[TM], woff[TN];                            // per-lane constant byte offsets of the fragment reads
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int p = wm * 128 + j * 16 + lr;
     const int img = p >> (g.ltw + g.lth), py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
-    hbase[j] = img * g.hp + py * g.hw + px;
+    xoff[j] = (img * g.hp + py * g.hw + px) * 64 + lq * 16;
   }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) woff[i] = lds64_off(wn * 64 + i * 16 + lr, lq);
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -172,9 +178,9 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
     // W fragments first, then X; MFMAs in j-major order so the first ones need only wf[*] + xf[0] and the
     // counted lgkmcnt waits let the matrix pipe start while the later X fragments are still arriving
 #pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + lds64_off(wn * 64 + i * 16 + lr, lq));
+    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff[i]);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + lds64_off(hbase[j] + tapoff, lq));
+    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + tapoff * 64 + xoff[j]);
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
