@@ -2,18 +2,27 @@
 //
 // Why: the tap-refetch implicit GEMM (igemm_pipe.hip) re-reads every input pixel 9 times from
 // L2 — rocprofv3 showed its waves parked on vmcnt/barrier 51 % of the time at ~20-30 GB/s of
-// LDS-DMA per CU.  Here LDS is the reuse level for the taps: a workgroup owns 512 output pixels
-// (nimg x th x tw patch, e.g. 16 rows x 32 of one 32x32 image) x 128 couts and, per 64-byte
-// channel chunk (32 bf16/f16 or 16 f32 channels), brings the (th+2)x(tw+2) input halo ONCE into
-// LDS; the 9 taps are just 9 different row offsets of the MFMA B-operand fragment reads.
-// HBM/L2 -> LDS traffic per 512 pixels per chunk: halo 38 KB + 9 weight tiles x 8 KB = 110 KB,
-// vs 9 x (32+8) KB = 360 KB for tap refetch.
+// LDS-DMA per CU.  Here LDS is the reuse level for the taps: a workgroup owns an output patch
+// (ni images x th x tw pixels) x 128 couts and, per 64-byte channel chunk (32 bf16/f16 or 16 f32
+// channels), brings the (th+2)x(tw+2) input halo ONCE into LDS; the 9 taps are just 9 different
+// row offsets of the MFMA B-operand fragment reads.
 //
-//   X halo: double-buffered per channel chunk (the next chunk's halo is fetched during the
-//           current chunk's 9 taps); W[tap] tiles: 4-stage ring, prefetch distance 3 taps.
-//   all transfers are LDS-DMA (global_load_lds_dwordx4), counted vmcnt, one s_barrier per tap.
-//   8 waves as 4(M) x 2(N); wave tile 128 pixels x 64 couts (32 MFMA 16x16x32 per tap).
-//   padding / out-of-range images read a zero page; epilogue staged through LDS (two half passes).
+// Two geometries of the same kernel (template NW = waves per workgroup):
+//   NW = 4: 256-pixel patch, 4 waves as 2(M) x 2(N), ~76 KiB of LDS -> TWO workgroups per CU.  One
+//           workgroup's HBM-bound prologue / epilogue overlaps the other's MFMA loop, and the two
+//           waves that share a SIMD belong to different workgroups, so they are not barrier-locked
+//           into reading fragments and issuing MFMAs at the same moments (the 8-wave form measured
+//           ~2,000 cycles per tap against 1,024 of MFMA work).  [default]
+//   NW = 8: 512-pixel patch, 8 waves as 4(M) x 2(N), 147 KiB, one workgroup per CU: half the weight
+//           traffic per pixel (DCAMD_HALO_NW=8 selects it).
+//   Wave tile 128 pixels x 64 couts (32 MFMA 16x16x32 per tap) in both.
+//
+//   X halo: double-buffered per channel chunk (the next chunk's halo is fetched during the current
+//           chunk's 9 taps), stored un-swizzled so a fragment address is "per-lane constant + tap offset";
+//   W[tap] tiles (128 couts x 64 B): 4-stage ring, prefetch distance 3 taps, XOR-swizzled.
+//   All transfers are LDS-DMA (global_load_lds_dwordx4), counted vmcnt, one s_barrier per tap.
+//   Padding / out-of-range images read a zero page; epilogue staged through LDS (two passes).
+#include <stdlib.h>
 #include "igemm_epilogue.h"
 
 static __device__ chunk16 g_zero_page[16];   // per translation unit (no device-side linking)
@@ -22,25 +31,31 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct HaloGeom {
-  int ltw, lth, lni;        // log2 of tile width / height / images per tile (tw*th*ni == 512)
+  int ltw, lth, lni;        // log2 of tile width / height / images per tile (tw*th*ni == NW*64)
   int tiles_x, tiles_y;     // tiles per image
   int hw, hp, HR, nxl;      // halo width, halo pixels per image patch, halo rows per tile, X loads per lane
   int n_img, H, W;
 };
 
-constexpr int HALO_NXL = 6;                             // LDS-DMA instructions per lane per halo (16x16 images: 2 x 18 x 18 rows)
-constexpr int HALO_XROWS_MAX = HALO_NXL * 128;
-constexpr int HALO_XBUF = HALO_NXL * 512 * 16;          // bytes per X halo buffer
+constexpr int HALO_NXL = 6;                             // max LDS-DMA instructions per lane per halo
 constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
-constexpr int HALO_LDS_MAIN = 2 * HALO_XBUF + 4 * HALO_WST;
 constexpr int HALO_OLD = 128 + 4;                       // epilogue staging row (floats)
-constexpr int HALO_LDS_EPI = 256 * HALO_OLD * 4;
-constexpr int HALO_LDS = HALO_LDS_MAIN > HALO_LDS_EPI ? HALO_LDS_MAIN : HALO_LDS_EPI;
 
-// 64-byte rows: 4 rows per 256-B bank row.  ds_read_b128 is served in 16-lane groups that MIX two values of
-// lane>>4 (lanes {0-3,12-15} of one quad with {20-27} of the next), so the chunk swizzle must keep
-// g(q) = [0,2,3,1][(row>>2)&3]: then the 16 rows x 2 chunks of every service group hit 16 distinct 16-B slots
-// (the plain (row>>2)&3 XOR measured 42 % of LDS cycles as bank conflicts).
+template <int NW> struct HaloCfg {
+  static constexpr int NT = NW * 64;                    // threads
+  static constexpr int PIX = NW * 64;                   // output pixels per workgroup
+  static constexpr int XBUF = HALO_NXL * NT * 16;       // bytes per X halo buffer (NXL instructions x NT lanes x 16 B)
+  static constexpr int XROWS = HALO_NXL * NT / 4;
+  static constexpr int WLD = 512 / NT;                  // W LDS-DMA instructions per lane per tap (8 KiB tile)
+  static constexpr int WR = NW == 4 ? 3 : 4;            // W ring stages (prefetch distance WR-1 taps); 3 keeps NW=4 at 72 KiB -> 2 per CU
+  static constexpr int LDS_MAIN = 2 * XBUF + WR * HALO_WST;
+  static constexpr int EROWS = PIX / 2;                 // staging rows per epilogue pass
+  static constexpr int LDS_EPI = EROWS * HALO_OLD * 4;
+  static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+};
+
+// W tile: 64-byte rows, 4 rows per 256-B bank row.  ds_read_b128 is served in 16-lane groups that MIX two values
+// of lane>>4, so the chunk swizzle is g(q) = [0,2,3,1][(row>>2)&3] (conflict-free for every service group).
 __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 __device__ __forceinline__ int lds64_off(int row, int chunk) { return row * 64 + ((chunk ^ swz64(row)) << 4); }
 
@@ -53,21 +68,23 @@ extern "C" void dc_debug_set_stamps(unsigned long long* p) { (void)hipMemcpyToSy
 #define DC_STAMP(k) do {} while (0)
 #endif
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void hwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
+  using Cfg = HaloCfg<NW>;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKE = 4 * EPC;                  // channels per 64-byte chunk row
   constexpr int TM = 8, TN = 4;
+  constexpr int NT = Cfg::NT, WLD = Cfg::WLD, WR = Cfg::WR, PD = Cfg::WR - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Wring = smem + 2 * HALO_XBUF;
+  char* const Wring = smem + 2 * Cfg::XBUF;
 
   DC_STAMP(0);
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;      // NW/2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
   tile_of_block(a, tile_m, tile_n);
@@ -79,17 +96,13 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
   const int Ctot = a.C0 + a.C1;
   const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
 
-  // ---- X loader: lane fetches LDS position p = i*512 + t  -> halo row p>>2, physical chunk p&3 ----
+  // ---- X loader: lane fetches LDS position p = i*NT + t  -> halo row p>>2, chunk p&3 (image is not swizzled) ----
   constexpr int NXL = HALO_NXL;
   int prow0[NXL], prow1[NXL];                   // source pixel row (sample*H*W + y*W + x) per source, -1 = zero page
-  // X halo image is stored UN-swizzled ([row][4 chunks]): its fragment reads are 2-way bank conflicted, but the read
-  // address of (pixel tile j, tap) becomes one add of a wave-uniform tap offset to a per-lane constant.  (The swizzled
-  // image needed ~10 VALU per read: rocprofv3 counted 4.4 VALU per MFMA and instruction issue at 38 % of wave time.)
   const int xlx = t & 3;
-  const int xl = (t & 3) ^ swz64(t >> 2);       // W tile keeps the swizzle: logical chunk of row t>>2
 #pragma unroll
   for (int i = 0; i < NXL; ++i) {
-    const int hr = (i * 512 + t) >> 2;
+    const int hr = (i * NT + t) >> 2;
     prow0[i] = -1; prow1[i] = -1;
     if (i < g.nxl && hr < g.HR) {
       const int img = hr / g.hp, r = hr - img * g.hp;
@@ -111,27 +124,35 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
     const T* src = reinterpret_cast<const T*>(s1 ? a.src1 : a.src0);
     const int ld = s1 ? a.ld1 : a.ld0;
     const int coff = (s1 ? cc - c0chunks : cc) * BKE + xlx * EPC;
-    char* xs = smem + (cc & 1) * HALO_XBUF + wave * 1024;
+    char* xs = smem + (cc & 1) * Cfg::XBUF + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       if (i < g.nxl) {
         const int pr = s1 ? prow1[i] : prow0[i];
         const size_t e = (size_t)(pr < 0 ? 0 : pr) * ld + coff;
         const char* gp = pr < 0 ? zero : reinterpret_cast<const char*>(src + e);
-        __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
       }
     }
   };
-  // ---- W loader: 128 couts x 64 B per (chunk, tap): position t -> row t>>2, phys chunk t&3 ----
-  const T* wrow = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128 + (t >> 2)) * a.Ktot + xl * EPC;
+  // ---- W loader: 128 couts x 64 B per (chunk, tap): position i*NT + t -> row >>2, phys chunk &3 (swizzled) ----
+  const T* wrow[WLD];
+#pragma unroll
+  for (int i = 0; i < WLD; ++i) {
+    const int row = (i * NT + t) >> 2;
+    wrow[i] = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128 + row) * a.Ktot + ((t & 3) ^ swz64(row)) * EPC;
+  }
   auto issue_w = [&](int s) {                       // s = cc*9 + tap
     const int cc = s / 9, tap = s - cc * 9;
-    const char* gp = reinterpret_cast<const char*>(wrow + (size_t)tap * Ctot + (size_t)cc * BKE);
-    __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(Wring + (s & 3) * HALO_WST + wave * 1024), 16, 0, 0);
+    const size_t koff = (size_t)tap * Ctot + (size_t)cc * BKE;
+#pragma unroll
+    for (int i = 0; i < WLD; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wrow[i] + koff),
+                                       (lptr_t)(Wring + (s % WR) * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
   };
 
-  // ---- fragment row bases: output pixel p = wm*128 + j*16 + lr -> top-left halo row of its 3x3 window ----
-  int xoff[TM], woff[TN];                            // per-lane constant byte offsets of the fragment reads
+  // ---- per-lane constant byte offsets of the fragment reads ----
+  int xoff[TM], woff[TN];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int p = wm * 128 + j * 16 + lr;
@@ -150,37 +171,39 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
   const int NS = nchunks * 9;
   DC_STAMP(1);
   issue_x(0);
-  issue_w(0);
-  issue_w(1);
-  issue_w(2);                                        // NS >= 9 always
+#pragma unroll
+  for (int i = 0; i < PD; ++i) issue_w(i);           // NS >= 9 always
   int tap = 0, cc = 0;
   for (int s = 0; s < NS; ++s) {
-    // W(s) (and X(cc) when tap == 0) must have landed; younger ops that may stay in flight:
-    // W(s+1), W(s+2) and, for tap in {1,2,3}, the nxl loads of X(cc+1) issued at tap 0.
+    // W(s) (and X(cc) when tap == 0) must have landed; younger LDS-DMA groups that may stay in flight:
+    // W(s+1), W(s+2) (WLD instructions each) and, for tap in {1,2,3}, the nxl loads of X(cc+1) issued at tap 0.
     const int rem = NS - 1 - s;
-    if (rem >= 2) {
-      const bool xfly = (tap >= 1 && tap <= 3) && (cc + 1 < nchunks);
-      if (!xfly) wait_vmcnt<2>();
-      else if (g.nxl == 5) wait_vmcnt<7>();
-      else if (g.nxl == 6) wait_vmcnt<8>();
-      else wait_vmcnt<2>();
-    } else if (rem == 1) wait_vmcnt<1>();
-    else wait_vmcnt<0>();
+    constexpr int FLY = (PD - 1) * WLD;               // W(s+1) .. W(s+PD-1)
+    if (rem >= PD - 1) {
+      const bool xfly = (tap >= 1 && tap <= PD) && (cc + 1 < nchunks);
+      if (!xfly) hwait_vmcnt<FLY>();
+      else if (g.nxl == 3) hwait_vmcnt<FLY + 3>();
+      else if (g.nxl == 4) hwait_vmcnt<FLY + 4>();
+      else if (g.nxl == 5) hwait_vmcnt<FLY + 5>();
+      else if (g.nxl == 6) hwait_vmcnt<FLY + 6>();
+      else hwait_vmcnt<FLY>();
+    } else if (rem == 1) hwait_vmcnt<WLD>();
+    else hwait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (s + 3 < NS) issue_w(s + 3);
+    if (s + PD < NS) issue_w(s + PD);
     if (tap == 0 && cc + 1 < nchunks) issue_x(cc + 1);
 
-    const char* Xb = smem + (cc & 1) * HALO_XBUF;
-    const char* Wst = Wring + (s & 3) * HALO_WST;
+    const char* Xb = smem + (cc & 1) * Cfg::XBUF;
+    const char* Wst = Wring + (s % WR) * HALO_WST;
     const int ky = tap / 3, kx = tap - ky * 3;
-    const int tapoff = ky * g.hw + kx;
+    const int tapoff = (ky * g.hw + kx) * 64;
     chunk16 xf[TM], wf[TN];
     // W fragments first, then X; MFMAs in j-major order so the first ones need only wf[*] + xf[0] and the
     // counted lgkmcnt waits let the matrix pipe start while the later X fragments are still arriving
 #pragma unroll
     for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff[i]);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + tapoff * 64 + xoff[j]);
+    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + tapoff + xoff[j]);
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -189,7 +212,9 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
   }
 
   DC_STAMP(2);
-  // ---- epilogue: two half passes (256 rows each) through an fp32 LDS tile (igemm_epilogue.h) ----
+  // ---- epilogue: two passes (half of the patch each) through an fp32 LDS tile (igemm_epilogue.h) ----
+  constexpr int EROWS = Cfg::EROWS;                  // 256 (NW 8) / 128 (NW 4) rows per pass
+  constexpr int MW = NW / 4;                         // pixel-waves per pass
   float* otile = reinterpret_cast<float*>(smem);
   int samp[TM];
 #pragma unroll
@@ -200,11 +225,11 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
   for (int half = 0; half < 2; ++half) {
     __builtin_amdgcn_s_barrier();
     DC_STAMP(3 + 2 * half);
-    if ((wm >> 1) == half) epi_stage<TM, TN>(a, acc, otile, HALO_OLD, (wm & 1) * 128, wn * 64, tile_n * 128 + wn * 64, samp, lr, lq);
+    if (wm / MW == half) epi_stage<TM, TN>(a, acc, otile, HALO_OLD, (wm % MW) * 128, wn * 64, tile_n * 128 + wn * 64, samp, lr, lq);
     __syncthreads();
     DC_STAMP(4 + 2 * half);
-    epi_store<2>(a, otile, HALO_OLD, 256, 128, tile_n * 128, a.Cout, [&](int rloc, size_t& orow, size_t& rrow) {
-      const int p = half * 256 + rloc;
+    epi_store<2>(a, otile, HALO_OLD, EROWS, 128, tile_n * 128, a.Cout, [&](int rloc, size_t& orow, size_t& rrow) {
+      const int p = half * EROWS + rloc;
       const int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
       if (n >= g.n_img) return false;
       const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
@@ -219,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const IgemmArgs a, c
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-// true when the halo kernel can take this problem (3x3 stride 1, pow-2 extents >= 8, no GEGLU)
+// true when the halo kernel can take this problem (3x3 stride 1, pow-2 extents >= 16, no GEGLU)
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
   if (a.taps != 9 || a.stride != 1 || a.upsample || a.act == DC_ACT_GEGLU) return false;
   const int H = a.Hin, W = a.Win;
@@ -230,34 +255,41 @@ bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
   return true;
 }
 
-template <typename T>
+template <typename T, int NW>
 static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s) {
+  using Cfg = HaloCfg<NW>;
   static bool attr_done = false;
-  auto kern = conv3_halo_kernel<T>;
+  auto kern = conv3_halo_kernel<T, NW>;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_done = true;
   }
   IgemmArgs a = a0;
   HaloGeom g;
   g.H = a.Hin; g.W = a.Win; g.n_img = n_img;
   const int tw = g.W < 32 ? g.W : 32;
-  int th = 512 / tw; if (th > g.H) th = g.H;
-  const int ni = 512 / (tw * th);
+  int th = Cfg::PIX / tw; if (th > g.H) th = g.H;
+  const int ni = Cfg::PIX / (tw * th);
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
-  g.nxl = (g.HR * 4 + 511) / 512;
-  if (g.HR > HALO_XROWS_MAX || g.nxl > HALO_NXL) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
+  g.nxl = (g.HR * 4 + Cfg::NT - 1) / Cfg::NT;
+  if (g.HR > Cfg::XROWS || g.nxl > HALO_NXL || g.nxl < 3) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), HALO_LDS, s, a, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
 }
 
 int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s) {
-  if (dtype == DC_BF16) return launch_halo<__bf16>(a, n_img, s);
-  if (dtype == DC_F16) return launch_halo<_Float16>(a, n_img, s);
-  return launch_halo<float>(a, n_img, s);
+  static const int nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
+  if (nw == 8) {
+    if (dtype == DC_BF16) return launch_halo<__bf16, 8>(a, n_img, s);
+    if (dtype == DC_F16) return launch_halo<_Float16, 8>(a, n_img, s);
+    return launch_halo<float, 8>(a, n_img, s);
+  }
+  if (dtype == DC_BF16) return launch_halo<__bf16, 4>(a, n_img, s);
+  if (dtype == DC_F16) return launch_halo<_Float16, 4>(a, n_img, s);
+  return launch_halo<float, 4>(a, n_img, s);
 }
