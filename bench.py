@@ -131,8 +131,17 @@ def main():
     d = fam[dom]
     peak = PEAK_TFLOPS[args.dtype if "f32" not in dom else "f32"]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    # HBM traffic of that kernel from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled for the
+    # gfx950 half-count of wide streaming reads + WRITE_SIZE, per launch), recorded under profiles/
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf) and args.workload == "cifar10-unet-10x50" and args.dtype == "bf16":
+        rec_t = json.load(open(tf)).get(dom)
+        if rec_t:
+            traffic = round((2.0 * rec_t["fetch_kb_per_launch"] + rec_t["write_kb_per_launch"]) * 1024.0)
     roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=None, launches=d["launches"],
+                    frac=round(achieved / peak, 4), traffic=traffic, traffic_unit="HBM bytes/launch (PMC)",
+                    alg_bytes_per_launch=round(d["bytes"] / d["launches"]), launches=d["launches"],
                     avg_launch_ms=round(d["ms"] / d["launches"], 5),
                     alg_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 4))
     total_ms = sum(v["ms"] for v in fam.values())

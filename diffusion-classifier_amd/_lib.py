@@ -71,7 +71,7 @@ class Op(C.Structure):
 
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
-           "dc_igemm", "dc_igemm_cout_pad", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
+           "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
            "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_run_plan", "dc_run_plan_timed"]
 
 _lib = None
@@ -109,6 +109,8 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = argt
         fn.restype = i32
+    L.dc_igemm_variant.argtypes = [C.POINTER(IgemmParams)]
+    L.dc_igemm_variant.restype = C.c_char_p
     L.dc_igemm_cout_pad.argtypes = [i32, i32]
     L.dc_igemm_cout_pad.restype = i32
     L.dc_groupnorm_ws_floats.argtypes = [i32, i32, i32]

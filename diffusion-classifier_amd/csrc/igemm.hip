@@ -20,6 +20,7 @@
 // Block->tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) receive contiguous ranges of
 // the tile list, ordered M-fastest inside one N panel, so the workgroups sharing an L2 stream the
 // same weight panel.
+#include <stdio.h>
 #include <stdlib.h>
 #include "igemm_common.h"
 
@@ -159,7 +160,18 @@ extern "C" int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n) {
   return (cout + tn - 1) / tn * tn;
 }
 
-extern "C" int dc_igemm(const dc_igemm_params* p, dc_stream stream) {
+static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** variant);
+
+extern "C" int dc_igemm(const dc_igemm_params* p, dc_stream stream) { return igemm_run(p, stream, nullptr); }
+
+extern "C" const char* dc_igemm_variant(const dc_igemm_params* p) {
+  const char* v = "invalid";
+  (void)igemm_run(p, nullptr, &v);
+  return v;
+}
+
+// variant != nullptr: dry run — validate, pick the kernel, report its name, launch nothing.
+static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** variant) {
   DC_REQUIRE(p, DC_ERR_ARG, "dc_igemm: null params");
   DC_REQUIRE(p->dtype == DC_F32 || p->dtype == DC_BF16 || p->dtype == DC_F16, DC_ERR_DTYPE, "dc_igemm: dtype %d", p->dtype);
   DC_REQUIRE(p->taps == 1 || p->taps == 9, DC_ERR_ARG, "dc_igemm: taps must be 1 or 9 (got %d)", p->taps);
@@ -209,11 +221,24 @@ extern "C" int dc_igemm(const dc_igemm_params* p, dc_stream stream) {
   const int bn = p->tile_n;
   a.tiles_m = (a.M + 127) / 128;
   a.tiles_n = dc_igemm_cout_pad(p->Cout, bn) / bn;
+  static const bool no_nfast = getenv("DCAMD_NO_NFAST") != nullptr;
+  a.n_fast = (!no_nfast && a.tiles_n > 1 && (long long)dc_igemm_cout_pad(p->Cout, bn) * a.Ktot * dc_dtype_size(p->dtype) <= (2 << 20)) ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // tile_n 128: the LDS-DMA pipelined 256x128 kernel (igemm_pipe.hip).  DCAMD_IGEMM_V1=1 selects the
   // register-staged 128x128 kernel instead (A/B measurements; same results bit for bit).
   static const bool use_v1 = getenv("DCAMD_IGEMM_V1") != nullptr;
   static const bool no_halo = getenv("DCAMD_NO_HALO") != nullptr;
+  static const int halo_nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
+  static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
+  const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
+  if (variant) {
+    static thread_local char name[64];
+    if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, halo_nw == 8 ? 8 : 4);
+    else if (bn == 128 && !use_v1) snprintf(name, sizeof(name), a.nk <= light_nk ? "igemm_pipe<%s,128x128,2st>" : "igemm_pipe<%s,256x128,3st>", dn);
+    else snprintf(name, sizeof(name), "igemm<%s,128x%d>", dn, bn);
+    *variant = name;
+    return DC_OK;
+  }
   if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) return dc_conv3_halo_launch(a, p->dtype, p->n_img, s);
   if (bn == 128 && !use_v1) return dc_igemm_launch_pipe(a, p->dtype, s);
   if (bn == 128) {

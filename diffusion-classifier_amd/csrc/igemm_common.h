@@ -13,6 +13,7 @@ struct IgemmArgs {
   int C0, C1, ld0, ld1, rowvec_ld, gate_ld, res_dtype, res_ld, out_dtype, out_ld, act;
   int taps, stride, upsample, Hin, Win, Hout, Wout, Cout;
   int M, Ktot, c0chunks, cpt, nk, tiles_m, tiles_n;
+  int n_fast;   // tile order: 1 = N fastest (small weight matrix: every N tile of an M tile runs back to back, X read once)
 };
 
 template <typename T> struct Mma;
@@ -44,14 +45,21 @@ template <> struct Mma<float> {
 // the 256-B bank row (conflict-free for every 16-lane service group).
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// XCD-aware, bijective block -> (tile_m, tile_n): each XCD (private L2) gets a contiguous range of
-// the tile list, M fastest inside one N panel, so blocks sharing an L2 stream the same weight panel.
+// XCD-aware, bijective block -> (tile_m, tile_n): each XCD (private L2) gets a contiguous range of the tile
+// list.  Large weight matrices: M fastest inside one N panel, so blocks sharing an L2 stream the same weight
+// panel.  Small ones (<= 2 MiB, resident in every L2): N fastest, so the activation tile is fetched from HBM
+// once instead of once per N tile (the 16-tile GEGLU projection showed 4x the algorithmic FETCH_SIZE).
 __device__ __forceinline__ void tile_of_block(const IgemmArgs& a, int& tile_m, int& tile_n) {
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  tile_n = lid / a.tiles_m;
-  tile_m = lid - tile_n * a.tiles_m;
+  if (a.n_fast) {
+    tile_m = lid / a.tiles_n;
+    tile_n = lid - tile_m * a.tiles_n;
+  } else {
+    tile_n = lid / a.tiles_m;
+    tile_m = lid - tile_n * a.tiles_m;
+  }
 }
 
 // Epilogue of one wave: acc[i][j] is the 16x16 tile (cout block i, pixel block j); the lane holds 4

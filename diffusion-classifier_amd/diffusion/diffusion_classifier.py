@@ -145,9 +145,15 @@ class DiffusionClassifier(nn.Module):
         # fp32 on the host, one [BS] vector per trial exactly like the reference (:689-691): torch's CPU
         # kernels take different (vector / scalar-tail) code paths by element position, so evaluating the
         # whole [T,BS] grid at once would differ from the reference in the last bit.
-        logsnr = torch.stack([self.schedule(t_all[j].clone()) for j in range(T)])
-        alpha_all = torch.stack([torch.sqrt(torch.sigmoid(logsnr[j].clone())) for j in range(T)])
-        sigma_all = torch.stack([torch.sqrt(torch.sigmoid(-logsnr[j].clone())) for j in range(T)])
+        if rng == "philox" and t is None:
+            # throughput mode draws its own t anyway: one vectorised evaluation (last-bit differences from the
+            # per-trial form are irrelevant here and ~2 ms of host time per call are not)
+            logsnr = self.schedule(t_all)
+            alpha_all, sigma_all = torch.sqrt(torch.sigmoid(logsnr)), torch.sqrt(torch.sigmoid(-logsnr))
+        else:
+            logsnr = torch.stack([self.schedule(t_all[j].clone()) for j in range(T)])
+            alpha_all = torch.stack([torch.sqrt(torch.sigmoid(logsnr[j].clone())) for j in range(T)])
+            sigma_all = torch.stack([torch.sqrt(torch.sigmoid(-logsnr[j].clone())) for j in range(T)])
         draws = dict(logsnr=logsnr, alpha=alpha_all, sigma=sigma_all,
                      eps_of=eps_of, philox=(rng == "philox" and eps is None), seed=int(seed))
 
@@ -312,7 +318,9 @@ class _HipRunner:
             plan.ctx.copy_(dc.encoder.weight[:ncls].detach().to(dev, torch.float32))
         plan.run_ctx()                                   # per-class vectors: once per stage, not per micro-batch
         n_mb = -(-len(pairs) // n_bj)
-        host = torch.zeros((n_mb, sp["words"]), dtype=torch.int32).pin_memory()
+        host = sp.get("host")                            # pinned staging, reused across calls (pin_memory() is slow)
+        if host is None or host.shape[0] < n_mb:
+            host = sp["host"] = torch.zeros((n_mb, sp["words"]), dtype=torch.int32).pin_memory()
         dump = BS * ncls * T
         for m in range(n_mb):
             chunk = pairs[m * n_bj:(m + 1) * n_bj]

@@ -280,6 +280,8 @@ class PlanBuilder:
                 else:
                     setattr(s, name, v)
             self.structs.append(s)
+            if kind == L.OP_IGEMM:      # the kernel libdcamd picks for this shape (bench.py groups timings by it)
+                self.meta[i]["family"] = L.lib().dc_igemm_variant(s).decode()
             arr[i].kind = kind
             arr[i].params = C.cast(C.pointer(s), C.c_void_p)
         self.op_array = arr

@@ -100,6 +100,9 @@ typedef struct {
 } dc_igemm_params;
 int dc_igemm(const dc_igemm_params* p, dc_stream s);
 int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
+/* Name of the kernel dc_igemm would launch for these parameters, e.g. "conv3_halo<bf16,4w>",
+ * "igemm_pipe<bf16,256x128,3st>" (measurement / profiling only; static string). */
+const char* dc_igemm_variant(const dc_igemm_params* p);
 
 /* ---------------------------------------------------------------- norms ---------- */
 /* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.
