@@ -184,9 +184,7 @@ class DiffusionClassifier(nn.Module):
             batch = {k: v for k, v in batch.items()}
             x = batch["images"]
             p = batch["prompt"] if "prompt" in batch.keys() else None
-            if not classification:
-                raise NotImplementedError("sample() (DDPM generation, reference :210-293) is outside the scoring path")
-            sample = self.classify(x, p, fast=self.config.fast_classification)
+            sample = self.classify(x, p, fast=self.config.fast_classification) if classification else self.sample(x, p, from_t)
             if metrics is not None:
                 for metric in metrics:
                     metric.update((sample, batch))
@@ -196,8 +194,138 @@ class DiffusionClassifier(nn.Module):
                 break
         return val_samples, batches, metrics
 
+    # ---- generation (reference :163-293): the backbone calls run on the HIP forward, the ----
+    # ---- per-step sampler algebra is a handful of elementwise torch ops (not on the scoring path)          ----
+    def clip(self, x):
+        return torch.clamp(x, -1, 1)
+
+    @torch.no_grad()
+    def ddpm_sampler_step(self, z_t, pred, u_pred, logsnr_t, logsnr_s):
+        c = -torch.special.expm1(logsnr_t - logsnr_s)
+        alpha_t, alpha_s = torch.sqrt(torch.sigmoid(logsnr_t)), torch.sqrt(torch.sigmoid(logsnr_s))
+        sigma_t, sigma_s = torch.sqrt(torch.sigmoid(-logsnr_t)), torch.sqrt(torch.sigmoid(-logsnr_s))
+        w = self.cfg_w
+        pred = (1 + w) * pred - w * u_pred                                   # classifier-free guidance mix
+        x_pred = alpha_t * z_t - sigma_t * pred if self.pred_param == 'v' else (z_t - sigma_t * pred) / alpha_t
+        x_pred = self.clip(x_pred)
+        mu = alpha_s * (z_t * (1 - c) / alpha_t + c * x_pred)
+        return mu, (sigma_s ** 2) * c
+
+    @torch.no_grad()
     def sample(self, x, text=None, from_t=1):
-        raise NotImplementedError("sample() (DDPM generation, reference :210-293) is outside the scoring path (SURVEY §8f row 4)")
+        """Ancestral DDPM sampling with classifier-free guidance: two backbone evaluations per step
+        (class token / null token), same RNG consumption order as the reference."""
+        dev = x.device
+        if from_t == 1:
+            z_t = torch.randn(x.shape).to(dev)
+        else:
+            lam = self.schedule(torch.ones(x.shape[0]) * from_t).to(dev)
+            z_t, _ = self.diffuse(x, torch.sqrt(torch.sigmoid(lam)).view(-1, 1, 1, 1), torch.sqrt(torch.sigmoid(-lam)).view(-1, 1, 1, 1))
+        cond = null = None
+        if text is not None and self.encoder_type is not None:
+            cond = self.encode_text_prompt(text).to(dev)
+            null = self.encode_text_prompt(torch.full_like(text, self.null_token)).to(dev)
+        steps = torch.linspace(from_t, 0.0, self.config.sampling_steps + 1)
+        n = len(steps) - 1
+        for i in range(n + 1):                                                # the last pass repeats step n-1 and keeps the mean
+            u_t, u_s = (steps[i], steps[i + 1]) if i < n else (steps[-2], steps[-1])
+            lam_t, lam_s = self.schedule(u_t).to(dev).unsqueeze(0), self.schedule(u_s).to(dev).unsqueeze(0)
+            pred = self.ema(z_t, lam_t, encoder_hidden_states=cond)
+            u_pred = self.ema(z_t, lam_t, encoder_hidden_states=null)
+            mu, var = self.ddpm_sampler_step(z_t, pred, u_pred, lam_t.clone().detach(), lam_s.clone().detach())
+            if i == n:
+                return self.clip(mu)
+            z_t = mu + torch.randn_like(mu) * torch.sqrt(var)
+
+    # ---- inference driver and checkpoint ingest (reference :581-655, :769-805; SURVEY §8f rows 1-2) ----
+    @torch.no_grad()
+    def inference(self, optimizer=None, train_dataloader=None, val_dataloader=None, lr_scheduler=None, metrics=None,
+                  plot_function=None, classification=False, from_t=1, checkpoint_folder="checkpoints"):
+        """Same arguments and return value as the reference.  No accelerate object: the process's current HIP
+        device is used, batches are moved to it, metrics are summed over `torch.distributed` when initialised."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        if self.config.experiment_path is not None:
+            os.makedirs(os.path.join(self.config.experiment_path, "inference_images/"), exist_ok=True)
+            ckpt = os.path.join(self.config.experiment_path, checkpoint_folder)
+            if os.path.isdir(ckpt):
+                self.load_checkpoint(ckpt)
+        self.to(dev)
+        if metrics is not None:
+            for metric in metrics:
+                metric.set_device(dev)
+        self.model.eval()
+
+        def on_device(loader):
+            for batch in loader:
+                yield {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        val_samples, batches, metrics = self.evaluate(on_device(val_dataloader), metrics=metrics,
+                                                      stop_idx=self.config.evaluation_batches,
+                                                      classification=classification, from_t=from_t)
+        metric_output = []
+        if metrics is not None:
+            for metric in metrics:
+                metric.sync_across_processes(None)
+                metric_output.append(metric.get_output())
+        if plot_function is not None and not classification:
+            plot_function(output_dir=os.path.join(self.config.experiment_path, "inference_images/"), batches=batches,
+                          samples=val_samples, epoch=0, process_idx=D.world()[0])
+        return (metric_output, val_samples, batches) if metrics is not None else (val_samples, batches)
+
+    # accelerate.save_state layout written by the reference's training run (:382-386, :741): the prepared modules in
+    # registration order -> model.safetensors (backbone), model_1.safetensors (EMA wrapper: `ema_model.*`,
+    # `online_model.*`, `initted`, `step`), model_2.safetensors (nn.Embedding encoder: `weight`); plus
+    # experiment_state.pth {epoch, best_metric, experiment_key} (:744-752).
+    _CKPT_FILES = ("model", "model_1", "model_2")
+
+    @staticmethod
+    def _read_state(base):
+        if os.path.exists(base + ".safetensors"):
+            from safetensors.torch import load_file
+            return load_file(base + ".safetensors")
+        alt = base.replace("model", "pytorch_model", 1) + ".bin"      # accelerate with safe_serialization=False
+        if os.path.exists(alt):
+            return torch.load(alt, map_location="cpu", weights_only=True)
+        return None
+
+    def load_checkpoint(self, checkpoint_path, accelerator=None):
+        """Ingest a reference checkpoint directory.  Returns (epoch, best_metric) when experiment_state.pth exists."""
+        sd = self._read_state(os.path.join(checkpoint_path, "model"))
+        if sd is None:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {checkpoint_path}")
+        self.model.load_state_dict(sd)
+        ema_sd = self._read_state(os.path.join(checkpoint_path, "model_1"))
+        if ema_sd is not None:
+            inner = {k[len("ema_model."):]: v for k, v in ema_sd.items() if k.startswith("ema_model.")}
+            self.ema.ema_model.load_state_dict(inner)
+            for k in ("initted", "step"):
+                if k in ema_sd:
+                    getattr(self.ema, k).copy_(ema_sd[k].reshape(()))
+        else:
+            self.ema.ema_model.load_state_dict(sd)
+        enc_sd = self._read_state(os.path.join(checkpoint_path, "model_2"))
+        if enc_sd is not None and self.encoder is not None:
+            self.encoder.load_state_dict(enc_sd)
+        st = os.path.join(checkpoint_path, "experiment_state.pth")
+        if os.path.exists(st):
+            state = torch.load(st, map_location="cpu", weights_only=False)
+            print(f"Checkpoint loaded. Resuming from epoch {state.get('epoch')}. Best metric {state.get('best_metric')}")
+            return state.get("epoch"), state.get("best_metric")
+        return None, None
+
+    def save_checkpoint(self, checkpoint_dir, epoch=0, best_metric=None, experiment_key=None):
+        """Write the same directory layout (used for round trips and for handing weights back to the reference)."""
+        from safetensors.torch import save_file
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        cpu = lambda sd: {k: v.detach().cpu().contiguous() for k, v in sd.items()}
+        save_file(cpu(self.model.state_dict()), os.path.join(checkpoint_dir, "model.safetensors"))
+        ema_sd = {"ema_model." + k: v for k, v in self.ema.ema_model.state_dict().items()}
+        ema_sd.update({"online_model." + k: v for k, v in self.model.state_dict().items()})
+        ema_sd.update(initted=self.ema.initted.reshape(1), step=self.ema.step.reshape(1))
+        save_file(cpu(ema_sd), os.path.join(checkpoint_dir, "model_1.safetensors"))
+        if self.encoder is not None:
+            save_file(cpu(self.encoder.state_dict()), os.path.join(checkpoint_dir, "model_2.safetensors"))
+        torch.save({"epoch": epoch + 1, "best_metric": best_metric, "experiment_key": experiment_key},
+                   os.path.join(checkpoint_dir, "experiment_state.pth"))
 
 
 class _ForeignRunner:

@@ -134,7 +134,30 @@ def capture_schedules():
     print("schedules", {k: v.shape for k, v in arrs.items() if k != "t"})
 
 
+def capture_sample():
+    """Generation path (reference sample(), :210-293) with the stand-in backbone of the 1stage_eps case."""
+    g0 = dict(np.load(os.path.join(OUT, "classify_1stage_eps.npz")))
+    arrs = {}
+    for tag, pp, from_t, seed in [("eps", "eps", 1, 31), ("v_from_t", "v", 0.6, 37)]:
+        cfgd = base_cfg(pred_param=pp, cfg_w=1.5, sampling_steps=4)
+        bb = TinyBackbone(ch=3, hid=8, n_classes=cfgd["classes"], mode="nn")
+        bb.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g0.items() if k.startswith("bb.")})
+        dc = DiffusionClassifier(bb, Bag(**cfgd))
+        dc.encoder.weight.data.copy_(torch.from_numpy(g0["encoder.weight"]))
+        x = torch.from_numpy(g0["x"])
+        labels = torch.tensor([0, 1, 2, 3, 1])
+        torch.manual_seed(seed)
+        out = dc.sample(x, labels, from_t=from_t)
+        arrs.update({tag + ".x": x.numpy(), tag + ".labels": labels.numpy(), tag + ".out": out.numpy(),
+                     tag + ".seed": np.int64(seed), tag + ".from_t": np.float64(from_t)})
+        print("sample", tag, out.shape, float(out.abs().mean()))
+    np.savez_compressed(os.path.join(OUT, "sample_cases.npz"), **arrs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sample":
+        capture_sample()
+        sys.exit(0)
     os.makedirs(OUT, exist_ok=True)
     capture_schedules()
     capture_case("1stage_eps", {})
