@@ -37,15 +37,15 @@ struct HaloGeom {
   int n_img, H, W;
 };
 
-constexpr int HALO_NXL = 6;                             // max LDS-DMA instructions per lane per halo
 constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
 constexpr int HALO_OLD = 128 + 4;                       // epilogue staging row (floats)
 
 template <int NW> struct HaloCfg {
   static constexpr int NT = NW * 64;                    // threads
   static constexpr int PIX = NW * 64;                   // output pixels per workgroup
-  static constexpr int XBUF = HALO_NXL * NT * 16;       // bytes per X halo buffer (NXL instructions x NT lanes x 16 B)
-  static constexpr int XROWS = HALO_NXL * NT / 4;
+  static constexpr int NXL = NW == 4 ? 6 : 7;           // max LDS-DMA instructions per lane per halo (8x8 images: 8 x 100 rows)
+  static constexpr int XBUF = NXL * NT * 16;            // bytes per X halo buffer (NXL instructions x NT lanes x 16 B)
+  static constexpr int XROWS = NXL * NT / 4;
   static constexpr int WLD = 512 / NT;                  // W LDS-DMA instructions per lane per tap (8 KiB tile)
   static constexpr int WR = NW == 4 ? 3 : 4;            // W ring stages (prefetch distance WR-1 taps); 3 keeps NW=4 at 72 KiB -> 2 per CU
   static constexpr int LDS_MAIN = 2 * XBUF + WR * HALO_WST;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
 
   // ---- X loader: lane fetches LDS position p = i*NT + t  -> halo row p>>2, chunk p&3 (image is not swizzled) ----
-  constexpr int NXL = HALO_NXL;
+  constexpr int NXL = Cfg::NXL;
   int prow0[NXL], prow1[NXL];                   // source pixel row (sample*H*W + y*W + x) per source, -1 = zero page
   const int xlx = t & 3;
 #pragma unroll
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       else if (g.nxl == 4) hwait_vmcnt<FLY + 4>();
       else if (g.nxl == 5) hwait_vmcnt<FLY + 5>();
       else if (g.nxl == 6) hwait_vmcnt<FLY + 6>();
+      else if (g.nxl == 7) hwait_vmcnt<FLY + 7>();
       else hwait_vmcnt<FLY>();
     } else if (rem == 1) hwait_vmcnt<WLD>();
     else hwait_vmcnt<0>();
@@ -248,7 +249,7 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
   if (a.taps != 9 || a.stride != 1 || a.upsample || a.act == DC_ACT_GEGLU) return false;
   const int H = a.Hin, W = a.Win;
-  if (H < 16 || W < 16 || (H & (H - 1)) || (W & (W - 1))) return false;   // 8x8 and smaller stay on igemm_pipe (tiny, weight-bound)
+  if (H < 8 || W < 8 || (H & (H - 1)) || (W & (W - 1))) return false;     // 4x4 and smaller stay on igemm_pipe
   if ((long long)a.M >= (1LL << 31)) return false;
   const int bke = 64 / dc_dtype_size(dtype);
   if (a.C0 % bke || a.C1 % bke) return false;
@@ -274,7 +275,7 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s) {
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
   g.nxl = (g.HR * 4 + Cfg::NT - 1) / Cfg::NT;
-  if (g.HR > Cfg::XROWS || g.nxl > HALO_NXL || g.nxl < 3) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
+  if (g.HR > Cfg::XROWS || g.nxl > Cfg::NXL || g.nxl < 3) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
@@ -283,7 +284,10 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s) {
 }
 
 int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s) {
-  static const int nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
+  static const int nw_env = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
+  // 8x8 images: deep layers (Cout >= 256) are weight-traffic bound, so they take the 512-pixel patch (half the
+  // weight bytes per pixel); the 256-pixel patch would also need 4 x 100 halo rows = 7 loads per lane
+  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : nw_env;
   if (nw == 8) {
     if (dtype == DC_BF16) return launch_halo<__bf16, 8>(a, n_img, s);
     if (dtype == DC_F16) return launch_halo<_Float16, 8>(a, n_img, s);

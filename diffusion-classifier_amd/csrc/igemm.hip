@@ -233,7 +233,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
   if (variant) {
     static thread_local char name[64];
-    if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, halo_nw == 8 ? 8 : 4);
+    if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1) snprintf(name, sizeof(name), a.nk <= light_nk ? "igemm_pipe<%s,128x128,2st>" : "igemm_pipe<%s,256x128,3st>", dn);
     else snprintf(name, sizeof(name), "igemm<%s,128x%d>", dn, bn);
     *variant = name;
