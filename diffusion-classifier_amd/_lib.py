@@ -36,7 +36,8 @@ class IgemmParams(C.Structure):
                 ("rowvec", vp), ("rowvec_map", vp), ("rowvec_ld", i32), ("act", i32),
                 ("gate", vp), ("gate_map", vp), ("gate_ld", i32), ("pad2_", i32),
                 ("residual", vp), ("res_map", vp), ("res_dtype", i32), ("res_ld", i32),
-                ("out", vp), ("out_dtype", i32), ("out_ld", i32)]
+                ("out", vp), ("out_dtype", i32), ("out_ld", i32),
+                ("gn_scale", vp), ("gn_shift", vp), ("gn_silu", i32), ("pad3_", i32)]
 
 
 class GroupnormParams(C.Structure):
@@ -44,7 +45,7 @@ class GroupnormParams(C.Structure):
                 ("y", vp), ("dtype", i32), ("out_dtype", i32),
                 ("n", i32), ("HW", i32), ("C", i32), ("C1", i32), ("groups", i32), ("silu", i32),
                 ("splits", i32), ("eps", f32),
-                ("gamma", vp), ("beta", vp), ("ws", vp)]
+                ("gamma", vp), ("beta", vp), ("ws", vp), ("out_scale", vp), ("out_shift", vp)]
 
 
 class LayernormParams(C.Structure):
@@ -71,7 +72,7 @@ class Op(C.Structure):
 
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
-           "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
+           "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
            "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_run_plan", "dc_run_plan_timed"]
 
 _lib = None
@@ -111,6 +112,8 @@ def lib():
         fn.restype = i32
     L.dc_igemm_variant.argtypes = [C.POINTER(IgemmParams)]
     L.dc_igemm_variant.restype = C.c_char_p
+    L.dc_igemm_gn_fusable.argtypes = [C.POINTER(IgemmParams)]
+    L.dc_igemm_gn_fusable.restype = i32
     L.dc_igemm_cout_pad.argtypes = [i32, i32]
     L.dc_igemm_cout_pad.restype = i32
     L.dc_groupnorm_ws_floats.argtypes = [i32, i32, i32]

@@ -48,7 +48,9 @@ template <int NW> struct HaloCfg {
   static constexpr int XROWS = NXL * NT / 4;
   static constexpr int WLD = 512 / NT;                  // W LDS-DMA instructions per lane per tap (8 KiB tile)
   static constexpr int WR = NW == 4 ? 3 : 4;            // W ring stages (prefetch distance WR-1 taps); 3 keeps NW=4 at 72 KiB -> 2 per CU
-  static constexpr int LDS_MAIN = 2 * XBUF + WR * HALO_WST;
+  static constexpr int GNOFF = 2 * XBUF + WR * HALO_WST; // fused-GroupNorm affine of the workgroup's sample: scale[C], shift[C]
+  static constexpr int GNMAXC = 512;
+  static constexpr int LDS_MAIN = GNOFF + 2 * GNMAXC * 4;
   static constexpr int EROWS = PIX / 2;                 // staging rows per epilogue pass
   static constexpr int LDS_EPI = EROWS * HALO_OLD * 4;
   static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
@@ -119,6 +121,40 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   }
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (t & 3) * 16;
 
+  // ---- fused GroupNorm(+SiLU) prologue: y = act(x*scale[n][c] + shift[n][c]) applied IN PLACE on the landed halo ----
+  // (one sample per workgroup; every lane transforms exactly the 16-byte chunks it fetched, and skips padding rows,
+  //  which must stay 0 because the reference pads the NORMALISED tensor)
+  const bool gn = a.gn_scale != nullptr;
+  float* const gnp = reinterpret_cast<float*>(smem + Cfg::GNOFF);
+  if (gn) {
+    const int n0 = ng << g.lni;
+    if (n0 < g.n_img)
+      for (int c = t; c < Ctot; c += NT) {
+        gnp[c] = a.gn_scale[(size_t)n0 * Ctot + c];
+        gnp[Ctot + c] = a.gn_shift[(size_t)n0 * Ctot + c];
+      }
+    __syncthreads();
+  }
+  auto xform = [&](int ccx, int i) {
+    if (i < g.nxl && prow0[i] >= 0) {
+      chunk16* p = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (i * NT + t) * 16);
+      float f[EPC];
+      chunk_to_f<T>(*p, f);
+      const float* sc = gnp + ccx * BKE + xlx * EPC;
+      const float* sh = sc + Ctot;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float v = f[e] * sc[e] + sh[e];
+        if (a.gn_silu) {
+          if (sizeof(T) == 4) v = silu_f(v);                       // f32 parity path: accurate exp / divide
+          else v = v * __frcp_rn(1.0f + __expf(-v));               // 16-bit path: v_exp + v_rcp (result is rounded to 16 bit anyway)
+        }
+        f[e] = v;
+      }
+      *p = f_to_chunk<T>(f);
+    }
+  };
+
   auto issue_x = [&](int cc) {
     const bool s1 = cc >= c0chunks;
     const T* src = reinterpret_cast<const T*>(s1 ? a.src1 : a.src0);
@@ -173,6 +209,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   issue_x(0);
 #pragma unroll
   for (int i = 0; i < PD; ++i) issue_w(i);           // NS >= 9 always
+  if (gn) {                                          // chunk 0: transform before the first tap
+    hwait_vmcnt<PD * WLD>();                         // own X(0) loads have landed (the W groups may stay in flight)
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) xform(0, i);
+  }
   int tap = 0, cc = 0;
   for (int s = 0; s < NS; ++s) {
     // W(s) (and X(cc) when tap == 0) must have landed; younger LDS-DMA groups that may stay in flight:
@@ -190,6 +231,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       else hwait_vmcnt<FLY>();
     } else if (rem == 1) hwait_vmcnt<WLD>();
     else hwait_vmcnt<0>();
+    if (gn && tap == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my in-place writes of this chunk are in LDS
     __builtin_amdgcn_s_barrier();
     if (s + PD < NS) issue_w(s + PD);
     if (tap == 0 && cc + 1 < nchunks) issue_x(cc + 1);
@@ -209,6 +251,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    // X(cc+1) was issued at tap 0 and this lane's own pieces were waited for at tap PD+1: from then on transform
+    // one piece per tap, behind this tap's MFMAs (other waves read the buffer only after the next chunk's barrier)
+    if (gn && tap > PD && cc + 1 < nchunks) {
+      const int idx = tap - PD - 1;
+#pragma unroll
+      for (int i = 0; i < NXL; ++i)
+        if (i == idx) xform(cc + 1, i);              // static index: a runtime one would demote prow0[] to scratch
+    }
     if (++tap == 9) { tap = 0; ++cc; }
   }
 
@@ -254,6 +304,19 @@ bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
   const int bke = 64 / dc_dtype_size(dtype);
   if (a.C0 % bke || a.C1 % bke) return false;
   return true;
+}
+
+// fused GroupNorm prologue: one sample per workgroup, affine table fits its LDS slot, one halo piece per remaining tap
+bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype) {
+  if (!dc_conv3_halo_applicable(a, dtype)) return false;
+  static const int nw_env = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
+  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : (nw_env == 8 ? 8 : 4);
+  const int pix = nw * 64, nt = nw * 64, pd = (nw == 4 ? 3 : 4) - 1;
+  const int tw = a.Win < 32 ? a.Win : 32;
+  int th = pix / tw; if (th > a.Hin) th = a.Hin;
+  if (pix / (tw * th) != 1) return false;
+  const int hr = (th + 2) * (tw + 2), nxl = (hr * 4 + nt - 1) / nt;
+  return a.C0 + a.C1 <= 512 && nxl <= 8 - pd;
 }
 
 template <typename T, int NW>

@@ -164,6 +164,15 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
 
 extern "C" int dc_igemm(const dc_igemm_params* p, dc_stream stream) { return igemm_run(p, stream, nullptr); }
 
+extern "C" int32_t dc_igemm_gn_fusable(const dc_igemm_params* p) {
+  if (!p) return 0;
+  dc_igemm_params q = *p;
+  static const float dummy = 0.f;
+  q.gn_scale = &dummy; q.gn_shift = &dummy;
+  const char* v = nullptr;
+  return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
+}
+
 extern "C" const char* dc_igemm_variant(const dc_igemm_params* p) {
   const char* v = "invalid";
   (void)igemm_run(p, nullptr, &v);
@@ -211,6 +220,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   a.src0 = p->src0; a.map0 = p->map0; a.src1 = p->src1; a.map1 = p->map1; a.W = p->W; a.bias = p->bias;
   a.rowvec = p->rowvec; a.rowvec_map = p->rowvec_map; a.gate = p->gate; a.gate_map = p->gate_map;
   a.residual = p->residual; a.res_map = p->res_map; a.out = p->out;
+  a.gn_scale = p->gn_scale; a.gn_shift = p->gn_shift; a.gn_silu = p->gn_silu;
+  DC_REQUIRE((p->gn_scale == nullptr) == (p->gn_shift == nullptr), DC_ERR_ARG, "dc_igemm: gn_scale/gn_shift must both be set or null");
   a.C0 = p->C0; a.C1 = p->C1; a.ld0 = p->ld0 ? p->ld0 : p->C0; a.ld1 = p->ld1 ? p->ld1 : p->C1;
   a.rowvec_ld = p->rowvec_ld; a.gate_ld = p->gate_ld; a.res_dtype = p->res_dtype;
   a.res_ld = p->res_ld; a.out_dtype = p->out_dtype; a.out_ld = p->out_ld; a.act = p->act;
@@ -231,6 +242,12 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   static const int halo_nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
   static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
+  const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
+  if (a.gn_scale && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
+    if (variant) { *variant = "gn-not-fusable"; return DC_ERR_UNSUPPORTED; }
+    dc_set_error("dc_igemm: gn_scale/gn_shift given but this problem cannot take the fused GroupNorm prologue (see dc_igemm_gn_fusable)");
+    return DC_ERR_UNSUPPORTED;
+  }
   if (variant) {
     static thread_local char name[64];
     if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);

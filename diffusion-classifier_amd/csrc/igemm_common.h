@@ -10,6 +10,7 @@ struct IgemmArgs {
   const float* gate; const int32_t* gate_map;
   const void* residual; const int32_t* res_map;
   void* out;
+  const float* gn_scale; const float* gn_shift; int gn_silu;
   int C0, C1, ld0, ld1, rowvec_ld, gate_ld, res_dtype, res_ld, out_dtype, out_ld, act;
   int taps, stride, upsample, Hin, Win, Hout, Wout, Cout;
   int M, Ktot, c0chunks, cpt, nk, tiles_m, tiles_n;
@@ -138,4 +139,5 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s);
 // conv3_halo.hip
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype);
+bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype);   // fused GroupNorm prologue possible
 int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);

@@ -128,6 +128,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   }
 }
 
+// statistics-only mode: fold the split partials and emit the per-(sample, channel) affine for dc_igemm's fused prologue
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a, float* out_scale, float* out_shift) {
+  __shared__ float st[2 * 64];
+  const int C = a.C0 + a.C1, n = blockIdx.x, t = threadIdx.x;
+  const int cpg = C / a.groups;
+  for (int g = t; g < a.groups; g += 256) {
+    float S = 0.f, Q = 0.f;
+    for (int k = 0; k < a.splits; ++k) {
+      const float* w = a.ws + (((size_t)n * a.splits + k) * a.groups + g) * 2;
+      S += w[0]; Q += w[1];
+    }
+    const float cnt = (float)cpg * (float)a.HW;
+    const float mean = S / cnt;
+    const float var = fmaxf(Q / cnt - mean * mean, 0.f);
+    st[g] = mean; st[64 + g] = rsqrtf(var + a.eps);
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cpg;
+    const float r = st[64 + g] * a.gamma[c];
+    out_scale[(size_t)n * C + c] = r;
+    out_shift[(size_t)n * C + c] = a.beta[c] - st[g] * r;
+  }
+}
+
 extern "C" int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t splits) {
   return (int64_t)n * groups * splits * 2;
 }
@@ -141,7 +166,9 @@ extern "C" int32_t dc_groupnorm_splits(int32_t n, int32_t HW, int32_t C) {
 }
 
 extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
-  DC_REQUIRE(p && p->x && p->y && p->gamma && p->beta && p->ws, DC_ERR_ARG, "dc_groupnorm: null pointer");
+  DC_REQUIRE(p && p->x && p->gamma && p->beta && p->ws, DC_ERR_ARG, "dc_groupnorm: null pointer");
+  const bool stats_only = p->y == nullptr;
+  if (stats_only) DC_REQUIRE(p->out_scale && p->out_shift && p->groups <= 64, DC_ERR_ARG, "dc_groupnorm: statistics-only mode needs out_scale/out_shift and groups <= 64");
   const int C1 = p->C1;
   const int C = p->C + C1;
   const int epc = 16 / dc_dtype_size(p->dtype);
@@ -165,6 +192,14 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   const long long nb = (long long)p->splits * p->n;
   DC_REQUIRE(nb < (1LL << 31), DC_ERR_SHAPE, "dc_groupnorm: grid too large");
   dim3 grid((unsigned)nb), blk(256);
+  if (stats_only) {
+    if (p->dtype == DC_F32) hipLaunchKernelGGL((gn_stats_kernel<float>), grid, blk, lds_stats, s, a);
+    else if (p->dtype == DC_BF16) hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, blk, lds_stats, s, a);
+    else if (p->dtype == DC_F16) hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, blk, lds_stats, s, a);
+    else { dc_set_error("dc_groupnorm: dtype %d", p->dtype); return DC_ERR_DTYPE; }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->n), blk, 0, s, a, p->out_scale, p->out_shift);
+    return dc_check_launch("dc_groupnorm(stats)");
+  }
   if (p->dtype == DC_F32) {
     hipLaunchKernelGGL((gn_stats_kernel<float>), grid, blk, lds_stats, s, a);
     hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, blk, lds_apply, s, a);

@@ -113,7 +113,7 @@ class PlanBuilder:
 
     # ---- ops -----------------------------------------------------------------------
     def igemm(self, name, src0, W, Cout, *, taps=1, stride=1, upsample=0, src1=None, bias=None, rowvec=None,
-              act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None):
+              act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None, gn=None):
         dom = dom or self._dom(src0, src1, rowvec, gate, residual)
         Hin, Win = (src0.H * 2, src0.W * 2) if upsample else (src0.H, src0.W)
         if taps == 9:
@@ -134,6 +134,9 @@ class PlanBuilder:
                  res_dtype=residual.dt if residual is not None else 0,
                  res_ld=residual.ld if residual is not None else 0,
                  out=out, out_dtype=out.dt, out_ld=out.ld)
+        if gn is not None:       # fused GroupNorm(+SiLU) prologue: (scale, shift, silu) from groupnorm_stats
+            assert gn[0].dom == dom and gn[0].C == f["C0"] + f["C1"], "GroupNorm affine must live in the conv's domain"
+            f.update(gn_scale=gn[0], gn_shift=gn[1], gn_silu=int(gn[2]))
         if src1 is not None:
             assert src1.dt == src0.dt and (src1.H, src1.W) == (src0.H, src0.W)
         M = self.n[dom] * Hout * Wout
@@ -144,8 +147,36 @@ class PlanBuilder:
         meta = dict(name=name, family=f"igemm_{'f32' if f['dtype'] == L.DC_F32 else 'bf16' if f['dtype'] == L.DC_BF16 else 'f16'}_n{tile_n}",
                     flops=2.0 * M * kreal * Cout, bytes=float(in_bytes + kreal * Cout * es + M * cout_out * DT_SIZE[out.dt]),
                     M=M, N=Cout, K=kreal, taps=taps)
-        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual], [out], meta)
+        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []), [out], meta)
         return out
+
+    def gn_fusable(self, src0, src1, Cout):
+        """Can a 3x3 stride-1 conv of these sources take the GroupNorm prologue (dc_igemm_gn_fusable)?"""
+        if L.lib().dc_igemm_gn_fusable is None:
+            return False
+        fake = 1 << 20
+        p = L.IgemmParams(dtype=src0.dt, taps=9, stride=1, upsample=0, n_img=self.n[self._dom(src0, src1)], Hin=src0.H, Win=src0.W,
+                          Hout=src0.H, Wout=src0.W, src0=fake, C0=src0.C, ld0=src0.ld, src1=fake if src1 is not None else None,
+                          C1=src1.C if src1 is not None else 0, ld1=src1.ld if src1 is not None else 0, W=fake, Cout=Cout,
+                          tile_n=128, out=fake, out_dtype=src0.dt, out_ld=Cout)
+        return bool(L.lib().dc_igemm_gn_fusable(p))
+
+    def groupnorm_stats(self, name, x0, gamma, beta, groups, eps, x1=None):
+        """Statistics-only GroupNorm: returns the per-(sample, channel) scale / shift tensors for a fused conv prologue."""
+        dom = self._dom(x0, x1)
+        Cc = x0.C + (x1.C if x1 is not None else 0)
+        assert x0.ld == x0.C and (x1 is None or x1.ld == x1.C)
+        n, HW = self.n[dom], x0.H * x0.W
+        sc = self.tensor(name + ".scale", dom, 1, 1, Cc, L.DC_F32)
+        sh = self.tensor(name + ".shift", dom, 1, 1, Cc, L.DC_F32)
+        splits = L.lib().dc_groupnorm_splits(n, HW, Cc)
+        ws = TRef(name + ".ws", dom, 1, 1, 1, L.DC_F32, nbytes=round_up(L.lib().dc_groupnorm_ws_floats(n, groups, splits) * 4, 256))
+        f = dict(x=x0, map0=self._map(x0, dom), x1=x1, map1=self._map(x1, dom), y=None, dtype=x0.dt, out_dtype=x0.dt,
+                 n=n, HW=HW, C=x0.C, C1=x1.C if x1 is not None else 0, groups=groups, silu=0, splits=splits, eps=eps,
+                 gamma=gamma, beta=beta, ws=ws, out_scale=sc, out_shift=sh)
+        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1], [sc, sh, ws],
+                   dict(name=name, family="groupnorm_stats", flops=0.0, bytes=1.0 * n * HW * Cc * DT_SIZE[x0.dt]))
+        return sc, sh
 
     def groupnorm(self, name, x0, gamma, beta, groups, eps, silu, x1=None):
         dom = self._dom(x0, x1)
@@ -454,6 +485,8 @@ class UNetPlan:
     """
 
     def __init__(self, model, weights, n_bj, n_cls, n_ctx, *, share_trunk=True, score=None, device=None):
+        import os
+        fuse_gn = os.environ.get("DCAMD_NO_GN_FUSION") is None
         cfg = model.config
         dev = device or weights.dev
         dt = weights.dt
@@ -517,10 +550,22 @@ class UNetPlan:
 
         def resnet(key, x0, x1=None):
             Cout = P[key + ".conv1.b"].shape[0]
-            h = pb.groupnorm(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, True, x1=x1)
-            h = pb.igemm(key + ".conv1", h, pb.const(P[key + ".conv1.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
-                         rowvec=tproj.view(weights.tproj_off[key], Cout))
-            h = pb.groupnorm(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps, True)
+            tvec = tproj.view(weights.tproj_off[key], Cout)
+            # GroupNorm+SiLU is applied inside the conv's halo load where libdcamd can (the normalised tensor then never
+            # exists in HBM); otherwise as its own pass
+            if fuse_gn and pb.gn_fusable(x0, x1, Cout):
+                aff = pb.groupnorm_stats(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, x1=x1)
+                h = pb.igemm(key + ".conv1", x0, pb.const(P[key + ".conv1.w"]), Cout, taps=9, src1=x1,
+                             bias=pb.const(P[key + ".conv1.b"]), rowvec=tvec, gn=(aff[0], aff[1], True))
+            else:
+                h = pb.groupnorm(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, True, x1=x1)
+                h = pb.igemm(key + ".conv1", h, pb.const(P[key + ".conv1.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
+                             rowvec=tvec)
+            fuse2 = fuse_gn and pb.gn_fusable(h, None, Cout)
+            if fuse2:
+                aff2 = pb.groupnorm_stats(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps)
+            else:
+                h = pb.groupnorm(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps, True)
             if key + ".conv_shortcut.w" in P:
                 sc = pb.igemm(key + ".short", x0, pb.const(P[key + ".conv_shortcut.w"]), Cout, src1=x1,
                               bias=pb.const(P[key + ".conv_shortcut.b"]))
@@ -528,7 +573,7 @@ class UNetPlan:
                 assert x1 is None
                 sc = x0
             return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.b"]),
-                            residual=sc)
+                            residual=sc, gn=(aff2[0], aff2[1], True) if fuse2 else None)
 
         def transformer(key, x):
             Cc = x.C

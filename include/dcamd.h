@@ -97,12 +97,18 @@ typedef struct {
   const float* gate; const int32_t* gate_map; int32_t gate_ld, pad2_;
   const void* residual; const int32_t* res_map; int32_t res_dtype, res_ld;
   void* out; int32_t out_dtype, out_ld;
+  /* fused GroupNorm(+SiLU) prologue on the A operand: a[n,y,x,c] := act(a*gn_scale[n][c] + gn_shift[n][c]) for
+   * real pixels (conv padding stays 0).  Only where dc_igemm_gn_fusable() says so (3x3 halo kernel, one sample
+   * per workgroup, C0+C1 <= 512); NULL otherwise. */
+  const float* gn_scale; const float* gn_shift; int32_t gn_silu, pad3_;
 } dc_igemm_params;
 int dc_igemm(const dc_igemm_params* p, dc_stream s);
 int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
 /* Name of the kernel dc_igemm would launch for these parameters, e.g. "conv3_halo<bf16,4w>",
  * "igemm_pipe<bf16,256x128,3st>" (measurement / profiling only; static string). */
 const char* dc_igemm_variant(const dc_igemm_params* p);
+/* 1 when dc_igemm can take gn_scale/gn_shift for this problem (the other fields as for dc_igemm). */
+int32_t dc_igemm_gn_fusable(const dc_igemm_params* p);
 
 /* ---------------------------------------------------------------- norms ---------- */
 /* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.
@@ -113,6 +119,10 @@ typedef struct {
   void* y; int32_t dtype, out_dtype;    /* y: [n, HW, C+C1] */
   int32_t n, HW, C, C1, groups, silu, splits; float eps;
   const float* gamma; const float* beta; float* ws;
+  /* statistics-only mode (y == NULL): instead of normalising, write the per-(sample, channel) affine
+   * out_scale[n][C+C1] = rstd*gamma and out_shift = beta - mean*rstd*gamma, which dc_igemm applies on the
+   * fly (gn_scale / gn_shift) — the normalised tensor is then never written to HBM. */
+  float* out_scale; float* out_shift;
 } dc_groupnorm_params;
 int dc_groupnorm(const dc_groupnorm_params* p, dc_stream s);
 int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t splits);

@@ -394,3 +394,42 @@ def test_philox_normal_rows_are_keyed_by_id():
     L.check(lib.dc_philox_normal(ptr(big), 64, 65536, None, 7, L.stream_ptr()), "philox")
     assert abs(big.mean().item()) < 3e-3 and abs(big.std().item() - 1) < 3e-3
     assert abs((big ** 4).mean().item() - 3.0) < 0.05
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
+@pytest.mark.parametrize("concat", [False, True])
+def test_conv3x3_with_fused_groupnorm_prologue(dt, concat):
+    """GroupNorm statistics-only pass + conv whose halo load applies scale/shift + SiLU in place (padding stays 0)."""
+    torch.manual_seed(9)
+    g = E.bke(dt)
+    n, H, W, C0, C1, Cout = 3, 16, 16, 2 * g, (g if concat else 0), 128
+    q = lambda t: t.to(TD[dt]).float()
+    x0, x1 = q(torch.randn(n, C0, H, W) * 1.5 + 0.3), (q(torch.randn(n, C1, H, W)) if C1 else None)
+    xc = torch.cat([x0, x1], 1) if C1 else x0
+    Cc = C0 + C1
+    gamma, beta = torch.randn(Cc), torch.randn(Cc)
+    w = q(torch.randn(Cout, Cc, 3, 3) / (3 * Cc ** 0.5))
+    b = torch.randn(Cout)
+    hn = F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))
+    ref = F.conv2d(q(hn), w, b, padding=1)
+    lib = L.lib()
+    a0, a1 = nhwc(x0, dt), (nhwc(x1, dt) if C1 else None)
+    splits = lib.dc_groupnorm_splits(n, H * W, Cc)
+    ws = torch.zeros(lib.dc_groupnorm_ws_floats(n, 32, splits), device=DEV)
+    sc, sh = torch.zeros(n, Cc, device=DEV), torch.zeros(n, Cc, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    gp = L.GroupnormParams(x=ptr(a0), x1=ptr(a1), y=None, dtype=dt, out_dtype=dt, n=n, HW=H * W, C=C0, C1=C1, groups=32, silu=0,
+                           splits=splits, eps=1e-5, gamma=ptr(gd), beta=ptr(bd), ws=ptr(ws), out_scale=ptr(sc), out_shift=ptr(sh))
+    L.check(lib.dc_groupnorm(gp, L.stream_ptr()), "gn stats")
+    Wp, bb = E.pack_conv3x3(w, dt, DEV), b.to(DEV)
+    out = torch.full((n, H, W, Cout), float("nan"), dtype=TD[dt], device=DEV)
+    p = L.IgemmParams(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=C0,
+                      src1=ptr(a1), C1=C1, W=ptr(Wp), Cout=Cout, tile_n=128, bias=ptr(bb), out=ptr(out), out_dtype=dt, out_ld=Cout,
+                      gn_scale=ptr(sc), gn_shift=ptr(sh), gn_silu=1)
+    assert lib.dc_igemm_gn_fusable(p) == 1
+    L.check(lib.dc_igemm(p, L.stream_ptr()), "fused conv")
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert maxrel(got, ref) < (3e-5 if dt == L.DC_F32 else 1.5e-2), maxrel(got, ref)
+    p.Hin = p.Win = p.Hout = p.Wout = 4                       # 4x4 images are not on the halo kernel: fusion must be refused
+    assert lib.dc_igemm_gn_fusable(p) == 0 and lib.dc_igemm(p, L.stream_ptr()) == -6
