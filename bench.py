@@ -82,7 +82,9 @@ def main():
                ema_update_freq=1, encoder_type=enc, classes=classes, n_stages=1, evaluation_per_stage=[T],
                n_keep_per_stage=[1], n_fast_classes=2, fast_classification=False, compute_dtype=args.dtype,
                units_per_launch=args.units_per_launch)
-    dc = dca.DiffusionClassifier(backbone, dca.Config(**cfg))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints the parameter count (as the reference does): stdout carries the JSON line only
+        dc = dca.DiffusionClassifier(backbone, dca.Config(**cfg))
     dc.ema.ema_model.share_trunk = not args.no_share_trunk
     dc = dc.to(dev)
     B = ipg * world

@@ -84,3 +84,24 @@ __device__ __forceinline__ float load_as(const void* base, size_t idx, int dtype
 }
 
 static inline int dc_dtype_size(int dt) { return dt == DC_F32 ? 4 : 2; }
+
+// ---- asynchronous LDS fragment reads with hand-counted waits -------------------------------------------------
+// hipcc waits lgkmcnt(0) in front of the first MFMA that uses a ds_read result, and under register pressure it
+// even re-serialises "read, wait, 4 MFMA" (seen in the ISA of both GEMM kernels).  These helpers issue the reads
+// as opaque instructions and tie each counted wait to the registers it releases, so a block of N reads stays in
+// flight behind the MFMAs: LDS returns data in issue order, later-issued scalar loads only make a wait stricter.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ chunk16 ds_read16_async(uint32_t addr) {
+  chunk16 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+// lgkmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt / expcnt fields all ones = no wait): the compiler's own waitcnt
+// bookkeeping sees it, so it does not drop a second lgkmcnt(0) of its own into the middle of the asynchronous reads
+__device__ __forceinline__ void lgkm_fence0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+template <int N> __device__ __forceinline__ void lgkm_wait(chunk16& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lgkm_wait(chunk16& a, chunk16& b, chunk16& c, chunk16& d, chunk16& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}

@@ -21,8 +21,18 @@
 //           chunk's 9 taps), stored un-swizzled so a fragment address is "per-lane constant + tap offset";
 //   W[tap] tiles (128 couts x 64 B): 4-stage ring, prefetch distance 3 taps, XOR-swizzled.
 //   All transfers are LDS-DMA (global_load_lds_dwordx4), counted vmcnt, one s_barrier per tap.
-//   Padding / out-of-range images read a zero page; epilogue staged through LDS (two passes).
+//   Padding / out-of-range images read a zero page; the epilogue runs straight from the accumulators
+//   (igemm_epilogue.h): weight rows enter LDS permuted so that a lane ends up with runs of 8 consecutive couts.
 #include <stdlib.h>
+#include "common.h"
+#ifdef DC_STAMPS
+// diagnostic build only: per-block s_memtime stamps (never compiled into the shipped library)
+static __device__ unsigned long long* g_stamps;
+extern "C" void dc_debug_set_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#define DC_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DC_STAMP(k) do {} while (0)
+#endif
 #include "igemm_epilogue.h"
 
 static __device__ chunk16 g_zero_page[16];   // per translation unit (no device-side linking)
@@ -38,7 +48,6 @@ struct HaloGeom {
 };
 
 constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
-constexpr int HALO_OLD = 128 + 4;                       // epilogue staging row (floats)
 
 template <int NW> struct HaloCfg {
   static constexpr int NT = NW * 64;                    // threads
@@ -51,9 +60,7 @@ template <int NW> struct HaloCfg {
   static constexpr int GNOFF = 2 * XBUF + WR * HALO_WST; // fused-GroupNorm affine of the workgroup's sample: scale[C], shift[C]
   static constexpr int GNMAXC = 512;
   static constexpr int LDS_MAIN = GNOFF + 2 * GNMAXC * 4;
-  static constexpr int EROWS = PIX / 2;                 // staging rows per epilogue pass
-  static constexpr int LDS_EPI = EROWS * HALO_OLD * 4;
-  static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  static constexpr int LDS = LDS_MAIN;
 };
 
 // W tile: 64-byte rows, 4 rows per 256-B bank row.  ds_read_b128 is served in 16-lane groups that MIX two values
@@ -61,14 +68,6 @@ template <int NW> struct HaloCfg {
 __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 __device__ __forceinline__ int lds64_off(int row, int chunk) { return row * 64 + ((chunk ^ swz64(row)) << 4); }
 
-#ifdef DC_STAMPS
-// diagnostic build only: per-block s_memtime stamps (never compiled into the shipped library)
-static __device__ unsigned long long* g_stamps;
-extern "C" void dc_debug_set_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
-#define DC_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DC_STAMP(k) do {} while (0)
-#endif
 
 template <int N> __device__ __forceinline__ void hwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 #pragma unroll
   for (int i = 0; i < WLD; ++i) {
     const int row = (i * NT + t) >> 2;
-    wrow[i] = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128 + row) * a.Ktot + ((t & 3) ^ swz64(row)) * EPC;
+    wrow[i] = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128 + epi_wrow(row, false)) * a.Ktot + ((t & 3) ^ swz64(row)) * EPC;
   }
   auto issue_w = [&](int s) {                       // s = cc*9 + tap
     const int cc = s / 9, tap = s - cc * 9;
@@ -241,8 +240,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     const int ky = tap / 3, kx = tap - ky * 3;
     const int tapoff = (ky * g.hw + kx) * 64;
     chunk16 xf[TM], wf[TN];
-    // W fragments first, then X; MFMAs in j-major order so the first ones need only wf[*] + xf[0] and the
-    // counted lgkmcnt waits let the matrix pipe start while the later X fragments are still arriving
+    // W fragments first, then X; MFMAs in j-major order.  (Issuing all 12 reads asynchronously with counted lgkmcnt
+    // waits — as igemm_pipe.hip does — measured no faster here and costs ~20 VGPRs this kernel does not have: the
+    // second workgroup on the CU already fills the matrix pipe while this wave waits for a fragment.)
 #pragma unroll
     for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff[i]);
 #pragma unroll
@@ -263,41 +263,30 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   }
 
   DC_STAMP(2);
-  // ---- epilogue: two passes (half of the patch each) through an fp32 LDS tile (igemm_epilogue.h) ----
-  constexpr int EROWS = Cfg::EROWS;                  // 256 (NW 8) / 128 (NW 4) rows per pass
-  constexpr int MW = NW / 4;                         // pixel-waves per pass
-  float* otile = reinterpret_cast<float*>(smem);
-  int samp[TM];
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int n = (ng << g.lni) + ((wm * 128 + j * 16 + lr) >> (g.ltw + g.lth));
-    samp[j] = n < g.n_img ? n : 0;
-  }
-  for (int half = 0; half < 2; ++half) {
-    __builtin_amdgcn_s_barrier();
-    DC_STAMP(3 + 2 * half);
-    if (wm / MW == half) epi_stage<TM, TN>(a, acc, otile, HALO_OLD, (wm % MW) * 128, wn * 64, tile_n * 128 + wn * 64, samp, lr, lq);
-    __syncthreads();
-    DC_STAMP(4 + 2 * half);
-    epi_store<2>(a, otile, HALO_OLD, EROWS, 128, tile_n * 128, a.Cout, [&](int rloc, size_t& orow, size_t& rrow) {
-      const int p = half * EROWS + rloc;
-      const int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
-      if (n >= g.n_img) return false;
-      const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
-      const int rem = (ty * th + py) * g.W + tx * tw + px;
-      orow = (size_t)n * HW + rem;
-      rrow = (size_t)(a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
-      return true;
-    });
-  }
+  // ---- epilogue: straight from the accumulators (igemm_epilogue.h: the weight rows were loaded permuted) ----
+  const int nw0 = min((ng << g.lni) + ((wm * 128) >> (g.ltw + g.lth)), g.n_img - 1);
+  const int nw1 = min((ng << g.lni) + ((wm * 128 + 127) >> (g.ltw + g.lth)), g.n_img - 1);
+  epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, [&](int j, EpiRow& r) {
+    const int p = wm * 128 + j * 16 + lr;
+    int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
+    r.ok = n < g.n_img;
+    n = r.ok ? n : g.n_img - 1;
+    const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
+    const int rem = (ty * th + py) * g.W + tx * tw + px;
+    r.samp = n;
+    r.o = n * HW + rem;
+    r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
+  });
   DC_STAMP(7);
 }
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-// true when the halo kernel can take this problem (3x3 stride 1, pow-2 extents >= 16, no GEGLU)
+// true when the halo kernel can take this problem (3x3 stride 1, pow-2 extents >= 8, no activation / gate)
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
-  if (a.taps != 9 || a.stride != 1 || a.upsample || a.act == DC_ACT_GEGLU) return false;
+  // plain convolutions only (bias / per-sample row vector / residual): the 128-accumulator wave tile leaves room for ONE
+  // epilogue variant; an activation or a gate goes to igemm_pipe.hip (the UNets apply SiLU in the GroupNorm pass)
+  if (a.taps != 9 || a.stride != 1 || a.upsample || a.act != DC_ACT_NONE || a.gate) return false;
   const int H = a.Hin, W = a.Win;
   if (H < 8 || W < 8 || (H & (H - 1)) || (W & (W - 1))) return false;     // 4x4 and smaller stay on igemm_pipe
   if ((long long)a.M >= (1LL << 31)) return false;

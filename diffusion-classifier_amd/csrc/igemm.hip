@@ -237,7 +237,17 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // tile_n 128: the LDS-DMA pipelined 256x128 kernel (igemm_pipe.hip).  DCAMD_IGEMM_V1=1 selects the
   // register-staged 128x128 kernel instead (A/B measurements; same results bit for bit).
-  static const bool use_v1 = getenv("DCAMD_IGEMM_V1") != nullptr;
+  static const bool env_v1 = getenv("DCAMD_IGEMM_V1") != nullptr;
+  // the LDS-DMA kernels finish with the lane-resident epilogue (igemm_epilogue.h): whole 16-byte runs of 8 channels in
+  // and out.  Anything else (channel counts / leading dimensions that are not multiples of 8, unaligned side
+  // operands) takes the register-staged kernel, whose element-wise epilogue handles every case.
+  const bool lane_epi_ok = cout_out % 8 == 0 && p->out_ld % 8 == 0 && ((uintptr_t)p->out & 15) == 0 &&
+                           (!p->residual || (p->res_ld % 8 == 0 && ((uintptr_t)p->residual & 15) == 0)) &&
+                           (!p->bias || ((uintptr_t)p->bias & 15) == 0) &&
+                           (!p->rowvec || (((uintptr_t)p->rowvec & 15) == 0 && p->rowvec_ld % 4 == 0)) &&
+                           (!p->gate || (((uintptr_t)p->gate & 15) == 0 && p->gate_ld % 4 == 0 && p->act == DC_ACT_NONE)) &&
+                           (!p->residual || p->res_dtype == p->dtype) && (p->out_dtype == p->dtype || p->out_dtype == DC_F32);
+  const bool use_v1 = env_v1 || !lane_epi_ok;
   static const bool no_halo = getenv("DCAMD_NO_HALO") != nullptr;
   static const int halo_nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
   static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
@@ -251,12 +261,14 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   if (variant) {
     static thread_local char name[64];
     if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
+    else if (bn == 128 && !use_v1 && dc_igemm_xreg_applicable(a, p->dtype)) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
     else if (bn == 128 && !use_v1) snprintf(name, sizeof(name), a.nk <= light_nk ? "igemm_pipe<%s,128x128,2st>" : "igemm_pipe<%s,256x128,3st>", dn);
     else snprintf(name, sizeof(name), "igemm<%s,128x%d>", dn, bn);
     *variant = name;
     return DC_OK;
   }
   if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) return dc_conv3_halo_launch(a, p->dtype, p->n_img, s);
+  if (bn == 128 && !use_v1 && dc_igemm_xreg_applicable(a, p->dtype)) return dc_igemm_xreg_launch(a, p->dtype, s);
   if (bn == 128 && !use_v1) return dc_igemm_launch_pipe(a, p->dtype, s);
   if (bn == 128) {
     if (p->dtype == DC_BF16) return launch<__bf16, 128, 128, 2, 2>(a, s);

@@ -141,3 +141,6 @@ int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s);
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype);
 bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype);   // fused GroupNorm prologue possible
 int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);
+// igemm_xreg.hip: activation-stationary GEMM for K <= 256 (16-bit, 1 tap)
+bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype);
+int dc_igemm_xreg_launch(const IgemmArgs& a, int dtype, hipStream_t s);

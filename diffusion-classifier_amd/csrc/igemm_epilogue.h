@@ -1,177 +1,228 @@
-// igemm_epilogue.h — LDS-staged epilogue shared by igemm_pipe.hip and conv3_halo.hip.
+// igemm_epilogue.h — lane-resident epilogue shared by igemm_pipe.hip and conv3_halo.hip.
 //
-// phase 1 (epi_stage): a wave writes its accumulators (+bias, +per-sample row vector, activation,
-//   *gate) into an fp32 LDS tile.  Bias / row-vector / gate values are fetched as 16-byte vectors and
-//   ALL loads of a pixel row are issued before the first use (the first version fetched them one
-//   float at a time behind branches: s_memtime stamps showed 59 k cycles per 256-row pass there).
-// phase 2 (epi_store): 16 consecutive lanes cover one output row; residual rows are read and the
-//   result is written as one 16-byte access per chunk, residual loads issued four chunks ahead.
+// s_memtime stamps of the earlier LDS-staged epilogue: 34 k (no residual) to 49 k (residual) cycles of a
+// 114-156 k-cycle conv3_halo tile — four workgroup barriers, each behind the full latency of the residual
+// loads / output stores of only two waves per SIMD.  This version needs no LDS and no barrier:
+//
+//  * the weight rows of an N tile are PERMUTED on their way into LDS (epi_wrow, applied to the LDS-DMA source
+//    address), so that after the MFMAs a lane owns, for each of its pixels, runs of 8 CONSECUTIVE output
+//    channels: D row (lq*4 + reg) of cout fragment i is channel  wave_base + (i>>1)*32 + lq*8 + (i&1)*4 + reg.
+//    One 16-byte access per run (16-bit data), and the four lanes lq = 0..3 of a pixel cover 64 contiguous bytes;
+//  * GEGLU: fragments (2h, 2h+1) carry the value / gate rows of the same channels wave_base + lq*8 + h*4 + reg,
+//    so the product is formed in registers and a lane stores 8 consecutive outputs;
+//  * every load of the wave (residual chunks, bias, per-sample row vector / gate) is issued AND consumed before the
+//    first store (see epi_direct_act): no load ever queues behind a store acknowledgement.
 #pragma once
 #include "igemm_common.h"
+#ifndef DC_STAMP
+#define DC_STAMP(k) do {} while (0)   // conv3_halo.hip defines the diagnostic version (-DDC_STAMPS builds only)
+#endif
 
-// 4 consecutive floats p[0..3]; elements at index >= n_valid read as `fill` (channel tails)
-__device__ __forceinline__ f32x4 ld4(const float* p, bool vec, int n_valid, float fill) {
-  if (n_valid >= 4) {
-    if (vec) return *reinterpret_cast<const f32x4*>(p);
-    return f32x4{p[0], p[1], p[2], p[3]};
+// LDS row R (0..127) of the weight tile -> packed weight row of the N tile that must be loaded there
+__device__ __forceinline__ int epi_wrow(int R, bool geglu) {
+  const int wn = R >> 6, i = (R >> 4) & 3, lq = (R >> 2) & 3, reg = R & 3;
+  if (geglu) {
+    const int o = wn * 32 + lq * 8 + (i >> 1) * 4 + reg;           // output channel inside the tile (64 per tile)
+    return (o >> 4) * 32 + ((i & 1) << 4) + (o & 15);              // host packing: 16 value rows, 16 gate rows, ...
   }
-  f32x4 v = {fill, fill, fill, fill};
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (r < n_valid) v[r] = p[r];
-  return v;
+  return wn * 64 + (i >> 1) * 32 + lq * 8 + (i & 1) * 4 + reg;
 }
 
-// samp[j]: sample index of the lane's pixel in tile j (clamped to a valid sample for padded rows)
-// rloc0: first staging row of the wave; lc0: first staging column of the wave; pc0: first PACKED
-// global cout of the wave (bias/rowvec/gate index; == output channel unless GEGLU)
-// ACT is a template parameter on purpose: with a runtime `a.act` hipcc if-converted the activation
-// choice and evaluated expf + tanhf + erff for every element (43 k cycles per 256-row pass, stamped).
-template <int TM, int TN, int ACT>
-__device__ __forceinline__ void epi_stage_act(const IgemmArgs& a, f32x4 (&acc)[TN][TM], float* otile, int old_, int rloc0,
-                                              int lc0, int pc0, const int (&samp)[TM], int lr, int lq) {
+struct EpiRow { int o, r, samp; bool ok; };   // output row, residual row (units of one channel row; both < 2^31), sample
+
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+
+// acc[i][j]: cout fragment i (4 per wave), pixel fragment j; rowfn(j, EpiRow&) describes the lane's pixel of fragment j;
+// samp_first / samp_last: sample of the wave's first / last pixel (wave-uniform).  TWO_SAMP: the caller guarantees that
+// every pixel of the wave belongs to one of those two samples.
+// T = compute type of the kernel.  Preconditions (checked by the dispatcher, igemm.hip `lane_epi_ok`): output channels,
+// out_ld, res_ld multiples of 8; out / residual / bias / rowvec / gate 16-byte aligned; rowvec_ld, gate_ld multiples
+// of 4; the residual is stored as T and the output as T or fp32 (so no data-type branch sits inside the unrolled
+// loops: taken scalar branches cost ~20 cycles each on this core, and the first version had ten per store).
+//
+// vmcnt is ONE in-order counter for loads and stores on gfx9: a load issued after a store cannot be waited for
+// without also waiting for that store's acknowledgement (a first version that alternated "loads, math, stores" per
+// group of pixels spent 25-38 k cycles per conv tile exactly there).  Hence three phases: (A) per batch of (up to) four pixel
+// fragments: all loads, then the final fp32 values are formed IN PLACE in the accumulators; (B) only after the last
+// batch: conversions and stores, nothing left to wait for.
+template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn>
+__device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[4][TM], int tile_n, int wn, int lq,
+                                               int samp_first, int samp_last, RowFn rowfn) {
   constexpr bool geglu = ACT == DC_ACT_GEGLU;
-  const int cout_lim = a.Cout;                       // packed channel limit (GEGLU: value+gate rows)
-  const bool vb = a.bias && (((uintptr_t)a.bias & 15) == 0);
-  const bool vr = a.rowvec && (((uintptr_t)a.rowvec & 15) == 0) && ((a.rowvec_ld & 3) == 0);
-  const bool vg = a.gate && (((uintptr_t)a.gate & 15) == 0) && ((a.gate_ld & 3) == 0);
-  f32x4 bv[TN];
+  constexpr int NK = geglu ? 1 : 2;                  // 8-channel runs per pixel
+  constexpr int JB = TM % 4 == 0 ? 4 : TM;           // pixel fragments per load batch
+  const int cout_out = geglu ? (a.Cout >> 1) : a.Cout;
+  const int c0 = (geglu ? tile_n * 64 + wn * 32 : tile_n * 128 + wn * 64) + lq * 8;     // run k starts at c0 + 32 k
+  constexpr bool res16 = sizeof(T) == 2;
+  bool con[NK];                                      // run k holds real channels
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int pc = pc0 + i * 16 + lq * 4;
-    bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bv[i] = ld4(a.bias + pc, vb, cout_lim - pc, 0.f);
-  }
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int rloc = rloc0 + j * 16 + lr;
-    f32x4 rvv[TN], gtv[TN];
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int pc = pc0 + i * 16 + lq * 4;
-      rvv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gtv[i] = f32x4{1.f, 1.f, 1.f, 1.f};
-      if (a.rowvec)
-        rvv[i] = ld4(a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[samp[j]] : samp[j]) * a.rowvec_ld + pc, vr, cout_lim - pc, 0.f);
-      if (a.gate)
-        gtv[i] = ld4(a.gate + (size_t)(a.gate_map ? a.gate_map[samp[j]] : samp[j]) * a.gate_ld + pc, vg, cout_lim - pc, 1.f);
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      f32x4 v;
-      int lc;
-      if (geglu) {
-        if (i & 1) continue;
-        lc = ((lc0 + i * 16) >> 1) + lq * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bv[i][r]) * gelu_erf_f(acc[(i + 1) % TN][j][r] + bv[(i + 1) % TN][r]);
-      } else {
-        lc = lc0 + i * 16 + lq * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = acc[i][j][r] + bv[i][r] + rvv[i][r];
-          if (ACT == DC_ACT_SILU) x = silu_f(x);
-          if (ACT == DC_ACT_GELU_TANH) x = gelu_tanh_f(x);
-          v[r] = x * gtv[i][r];
-        }
-      }
-      *reinterpret_cast<f32x4*>(otile + rloc * old_ + lc) = v;
-    }
-  }
-}
+  for (int k = 0; k < NK; ++k) con[k] = c0 + 32 * k < cout_out;
 
-template <int TM, int TN>
-__device__ __forceinline__ void epi_stage(const IgemmArgs& a, f32x4 (&acc)[TN][TM], float* otile, int old_, int rloc0,
-                                          int lc0, int pc0, const int (&samp)[TM], int lr, int lq) {
-  switch (a.act) {   // wave-uniform
-    case DC_ACT_SILU: epi_stage_act<TM, TN, DC_ACT_SILU>(a, acc, otile, old_, rloc0, lc0, pc0, samp, lr, lq); break;
-    case DC_ACT_GEGLU: epi_stage_act<TM, TN, DC_ACT_GEGLU>(a, acc, otile, old_, rloc0, lc0, pc0, samp, lr, lq); break;
-    case DC_ACT_GELU_TANH: epi_stage_act<TM, TN, DC_ACT_GELU_TANH>(a, acc, otile, old_, rloc0, lc0, pc0, samp, lr, lq); break;
-    default: epi_stage_act<TM, TN, DC_ACT_NONE>(a, acc, otile, old_, rloc0, lc0, pc0, samp, lr, lq); break;
-  }
-}
-
-// RowFn: (int rloc, size_t& out_row, size_t& res_row) -> bool valid   (rows in elements of one channel row)
-template <int ES, int UNR, typename RowFn>
-__device__ __forceinline__ void epi_store_es(const IgemmArgs& a, const float* otile, int old_, int rows, int tcols, int col0,
-                                             int cout_out, RowFn rowfn) {
-  const int t = threadIdx.x, nt = blockDim.x;
-  const int cpr = tcols / ES;
-  const int total = rows * cpr;
-  const bool res16 = a.residual && a.res_dtype != DC_F32;
-  // vector path: whole 16-byte chunks in and out (a 16-bit residual under an f32 output would be an
-  // 8-byte read: left to the element path)
-  const bool vec_ok = (cout_out % ES == 0) && (a.out_ld % ES == 0) && (!a.residual || ((a.res_ld % ES == 0) && !(res16 && ES == 4)));
-  for (int base = t; base < total; base += UNR * nt) {
-    bool ok[UNR]; size_t o[UNR], rr[UNR]; int ch[UNR], rl[UNR];
-    chunk16 rc[UNR][2];
+  // ---- phase A1: bias + per-sample row vector, added into the accumulators (their registers are free again before
+  // the residual chunks are fetched).  Packed bias index: GEGLU value rows at (c>>4)*32 + (c&15), gate rows 16 further.
+  {
+    float bs[NK][8], bgt[8];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int idx = base + u * nt;
-      ok[u] = false; o[u] = 0; rr[u] = 0; ch[u] = 0; rl[u] = 0;
-      rc[u][0] = chunk16{0u, 0u, 0u, 0u}; rc[u][1] = rc[u][0];
-      if (idx < total) {
-        rl[u] = idx / cpr; ch[u] = idx - rl[u] * cpr;
-        const int c = col0 + ch[u] * ES;
-        ok[u] = rowfn(rl[u], o[u], rr[u]) && c < cout_out;
-        o[u] = o[u] * a.out_ld + c; rr[u] = rr[u] * a.res_ld + c;
-        if (ok[u] && a.residual && vec_ok) {
-          const char* rp = reinterpret_cast<const char*>(a.residual) + rr[u] * (res16 ? 2 : 4);
-          rc[u][0] = *reinterpret_cast<const chunk16*>(rp);                       // ES elems 16-bit = 16 B (ES 8) / 8 B (ES 4)
-          if (!res16 && ES == 8) rc[u][1] = *reinterpret_cast<const chunk16*>(rp + 16);
-        }
+    for (int k = 0; k < NK; ++k) {
+      const int c = c0 + 32 * k;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bs[k][e] = 0.f; if (k == 0) bgt[e] = 0.f; }
+      if (a.bias && con[k]) {
+        const int p = geglu ? (c >> 4) * 32 + (c & 15) : c;
+        ld8(a.bias + p, bs[k]);
+        if (geglu) ld8(a.bias + p + 16, bgt);
       }
     }
+    // one row-vector fetch for the wave when its pixels share a sample (samp_first == samp_last, both wave-uniform:
+    // a wave's pixels normally lie inside one image)
+    const bool uni = samp_first == samp_last;
+    if (!geglu && a.rowvec && uni) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (!ok[u]) continue;
-      const float* src = otile + rl[u] * old_ + ch[u] * ES;
-      float v[8];
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
-      f32x4 hi = {0.f, 0.f, 0.f, 0.f};
-      if (ES == 8) hi = *reinterpret_cast<const f32x4*>(src + 4);
+      for (int k = 0; k < NK; ++k)
+        if (con[k]) {
+          float rv[8];
+          ld8(a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[samp_first] : samp_first) * a.rowvec_ld + c0 + 32 * k, rv);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-      if (vec_ok) {
-        if (a.residual) {
-          float rf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (a.res_dtype == DC_F32) {
-            const f32x4 r0 = __builtin_bit_cast(f32x4, rc[u][0]), r1 = __builtin_bit_cast(f32x4, rc[u][1]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { rf[e] = r0[e]; rf[4 + e] = r1[e]; }
-          } else if (a.res_dtype == DC_BF16) chunk_to_f<__bf16>(rc[u][0], rf);
-          else chunk_to_f<_Float16>(rc[u][0], rf);
-#pragma unroll
-          for (int e = 0; e < ES; ++e) v[e] += rf[e];
+          for (int e = 0; e < 8; ++e) bs[k][e] += rv[e];
         }
-        if (a.out_dtype == DC_F32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o[u]) = f32x4{v[0], v[1], v[2], v[3]};
-          if (ES == 8) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o[u] + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else if (ES == 8) {
-          if (a.out_dtype == DC_BF16) *reinterpret_cast<chunk16*>(reinterpret_cast<__bf16*>(a.out) + o[u]) = f_to_chunk<__bf16>(v);
-          else *reinterpret_cast<chunk16*>(reinterpret_cast<_Float16*>(a.out) + o[u]) = f_to_chunk<_Float16>(v);
-        } else {
+    }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) store_as(a.out, o[u] + e, a.out_dtype, v[e]);
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (geglu) { acc[(e >> 2) * 2][j][e & 3] += bs[0][e]; acc[(e >> 2) * 2 + 1][j][e & 3] += bgt[e]; }
+        else {
+#pragma unroll
+          for (int k = 0; k < NK; ++k) acc[2 * k + (e >> 2)][j][e & 3] += bs[k][e];
         }
-      } else {
-        const int c = col0 + ch[u] * ES;
+      }
+    if (!geglu && a.rowvec && !uni) {
+      if (TWO_SAMP) {
+        // the wave's pixels belong to samp_first or samp_last only (images at least as large as the wave's pixel range:
+        // the dispatcher guarantees it): fetch both vectors, select per lane — no per-pixel address arithmetic
 #pragma unroll
-        for (int e = 0; e < ES; ++e)
-          if (c + e < cout_out) {
-            float x = v[e];
-            if (a.residual) x += load_as(a.residual, rr[u] + e, a.res_dtype);
-            store_as(a.out, o[u] + e, a.out_dtype, x);
+        for (int k = 0; k < NK; ++k)
+          if (con[k]) {
+            float ra[8], rb[8];
+            ld8(a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[samp_first] : samp_first) * a.rowvec_ld + c0 + 32 * k, ra);
+            ld8(a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[samp_last] : samp_last) * a.rowvec_ld + c0 + 32 * k, rb);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              EpiRow rj;
+              rowfn(j, rj);
+              const bool second = rj.samp != samp_first;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[2 * k + (e >> 2)][j][e & 3] += second ? rb[e] : ra[e];
+            }
           }
+      } else {                                 // any number of samples per wave (tiny images): one fetch per fragment
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          EpiRow rj;
+          rowfn(j, rj);
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+            if (con[k]) {
+              float rv[8];
+              ld8(a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[rj.samp] : rj.samp) * a.rowvec_ld + c0 + 32 * k, rv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[2 * k + (e >> 2)][j][e & 3] += rv[e];
+            }
+        }
       }
     }
   }
+
+  DC_STAMP(3);
+  int orow[TM];                                      // output row per pixel fragment, -1 = nothing to store
+  // ---- phase A2: per batch, residual chunks (and gates), then activation / gate / residual in place ----
+#pragma unroll
+  for (int j0 = 0; j0 < TM; j0 += JB) {
+    EpiRow row[JB];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) { rowfn(j0 + jj, row[jj]); orow[j0 + jj] = row[jj].ok ? row[jj].o : -1; }
+    // 16-bit residual: one 16-byte chunk per run; an fp32 residual (fp32 parity path only) is fetched at the point of
+    // use, still ahead of every store
+    chunk16 rc[JB][NK];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        rc[jj][k] = chunk16{0u, 0u, 0u, 0u};
+        if (res16 && a.residual && row[jj].ok && con[k])
+          rc[jj][k] = *reinterpret_cast<const chunk16*>(reinterpret_cast<const char*>(a.residual) + ((size_t)row[jj].r * a.res_ld + c0 + 32 * k) * 2);
+      }
+    if (j0 == 0) DC_STAMP(4);
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      const int j = j0 + jj;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        if (!(row[jj].ok && con[k])) continue;
+        float rf[8], gt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { rf[e] = 0.f; gt[e] = 1.f; }
+        if (GATE) ld8(a.gate + (size_t)(a.gate_map ? a.gate_map[row[jj].samp] : row[jj].samp) * a.gate_ld + c0 + 32 * k, gt);
+        if (a.residual) {
+          if (!res16) ld8(reinterpret_cast<const float*>(a.residual) + (size_t)row[jj].r * a.res_ld + c0 + 32 * k, rf);
+          else chunk_to_f<T>(rc[jj][k], rf);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (geglu) {       // value fragments 0 / 2 receive the product; the gate fragments are dead afterwards
+            acc[(e >> 2) * 2][j][e & 3] = acc[(e >> 2) * 2][j][e & 3] * gelu_erf_f(acc[(e >> 2) * 2 + 1][j][e & 3]) + rf[e];
+          } else {
+            float x = acc[2 * k + (e >> 2)][j][e & 3];
+            if (ACT == DC_ACT_SILU) x = silu_f(x);
+            if (ACT == DC_ACT_GELU_TANH) x = gelu_tanh_f(x);
+            if (GATE) x *= gt[e];
+            acc[2 * k + (e >> 2)][j][e & 3] = x + rf[e];
+          }
+        }
+      }
+    }
+  }
+  DC_STAMP(5);
+  // ---- phase B: conversions and stores only (one straight-line sequence per output type) ----
+  if (a.out_dtype == DC_F32) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        if (orow[j] >= 0 && con[k]) {
+          float* op = reinterpret_cast<float*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k;
+          if (geglu) { *reinterpret_cast<f32x4*>(op) = acc[0][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2][j]; }
+          else { *reinterpret_cast<f32x4*>(op) = acc[2 * k][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2 * k + 1][j]; }
+        }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        if (orow[j] >= 0 && con[k]) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = geglu ? acc[(e >> 2) * 2][j][e & 3] : acc[2 * k + (e >> 2)][j][e & 3];
+          *reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k) = f_to_chunk<T>(v);
+        }
+  }
 }
 
-template <int UNR = 4, typename RowFn>
-__device__ __forceinline__ void epi_store(const IgemmArgs& a, const float* otile, int old_, int rows, int tcols, int col0,
-                                          int cout_out, RowFn rowfn) {
-  // 16-bit outputs: 8 couts per 16-byte chunk; f32 outputs: 4
-  if (a.out_dtype == DC_F32) epi_store_es<4, UNR>(a, otile, old_, rows, tcols, col0, cout_out, rowfn);
-  else epi_store_es<8, UNR>(a, otile, old_, rows, tcols, col0, cout_out, rowfn);
+// A per-sample gate (DiT adaLN) only comes with DC_ACT_NONE (dispatcher: igemm.hip `lane_epi_ok`).
+template <typename T, int TM, typename RowFn>
+__device__ __forceinline__ void epi_direct(const IgemmArgs& a, f32x4 (&acc)[4][TM], int tile_n, int wn, int lq,
+                                           int samp_first, int samp_last, RowFn rowfn) {
+  switch (a.act) {   // wave-uniform
+    case DC_ACT_SILU: epi_direct_act<T, TM, DC_ACT_SILU, false, false>(a, acc, tile_n, wn, lq, samp_first, samp_last, rowfn); break;
+    case DC_ACT_GEGLU: epi_direct_act<T, TM, DC_ACT_GEGLU, false, false>(a, acc, tile_n, wn, lq, samp_first, samp_last, rowfn); break;
+    case DC_ACT_GELU_TANH: epi_direct_act<T, TM, DC_ACT_GELU_TANH, false, false>(a, acc, tile_n, wn, lq, samp_first, samp_last, rowfn); break;
+    default:
+      if (a.gate) epi_direct_act<T, TM, DC_ACT_NONE, true, false>(a, acc, tile_n, wn, lq, samp_first, samp_last, rowfn);
+      else epi_direct_act<T, TM, DC_ACT_NONE, false, false>(a, acc, tile_n, wn, lq, samp_first, samp_last, rowfn);
+      break;
+  }
 }

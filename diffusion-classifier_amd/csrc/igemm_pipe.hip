@@ -77,7 +77,11 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     // drain the LDS-DMA queue (vmcnt(0)) at its first use there
     asm volatile("" ::"v"(base0[i]), "v"(base1[i]));
   }
-  const T* wbase = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * BN + lrow) * a.Ktot + lchunk * EPC;
+  // weight rows enter LDS permuted (epi_wrow) so that the epilogue finds 8 consecutive couts per lane
+  const T* wbase = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * BN) * a.Ktot + lchunk * EPC;
+  int wro[WL];                                                // element offset of the W row behind LDS row lrow + RPI*i
+#pragma unroll
+  for (int i = 0; i < WL; ++i) wro[i] = epi_wrow(lrow + RPI * i, a.act == DC_ACT_GEGLU) * a.Ktot;
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (t & 7) * 16;
   const int Hm1 = a.Hin - 1, Wm1 = a.Win - 1;
 
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     char* ws = smem + st * STAGE + XST + wave * 1024;
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-      const char* gp = reinterpret_cast<const char*>(wbase + (size_t)(RPI * i) * a.Ktot + (size_t)ks * BKE);
+      const char* gp = reinterpret_cast<const char*>(wbase + wro[i] + ks * BKE);
       __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(ws + i * (NT * 16)), 16, 0, 0);
     }
     if (++icc == a.cpt) { icc = 0; ++itap; }
@@ -128,20 +132,36 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     if (ks + S - 1 < a.nk) issue(ks + S - 1);
     const char* Xs = smem + (ks % S) * STAGE;
     const char* Wsm = Xs + XST;
+    if (jmax == TM) {             // the hot path: every pixel tile of the wave is real
+      // all 16 fragment reads of the K-step go out first (asynchronous, common.h); the MFMAs follow in groups of
+      // four behind counted lgkmcnt waits, so the later fragments arrive under the running matrix pipe
+      const uint32_t xb = lds_addr_of(Xs), wb = lds_addr_of(Wsm);
+      chunk16 xf[2][TM], wf[2][TN];
+      lgkm_fence0();
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int c = sub * 4 + lq;
-      chunk16 xf[TM], wf[TN];
+      for (int sub = 0; sub < 2; ++sub) {
+        const int c = sub * 4 + lq;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wsm + lds_off(wn * 64 + i * 16 + lr, c));
-      if (jmax == TM) {           // the hot path: every pixel tile of the wave is real
+        for (int i = 0; i < TN; ++i) wf[sub][i] = ds_read16_async(wb + lds_off(wn * 64 + i * 16 + lr, c));
 #pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
+        for (int j = 0; j < TM; ++j) xf[sub][j] = ds_read16_async(xb + lds_off(wm * 64 + j * 16 + lr, c));
+      }
+#define PIPE_MMA_GROUP(SUB, J, NLEFT)                                                     \
+      lgkm_wait<NLEFT>(xf[SUB][J]);                                                         \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) acc[i][J] = Mma<T>::run(wf[SUB][i], xf[SUB][J], acc[i][J]);  \
+      __builtin_amdgcn_sched_barrier(0);
+      lgkm_wait<11>(wf[0][0], wf[0][1], wf[0][2], wf[0][3], xf[0][0]);
+      PIPE_MMA_GROUP(0, 0, 11) PIPE_MMA_GROUP(0, 1, 10) PIPE_MMA_GROUP(0, 2, 9) PIPE_MMA_GROUP(0, 3, 8)
+      lgkm_wait<3>(wf[1][0], wf[1][1], wf[1][2], wf[1][3], xf[1][0]);
+      PIPE_MMA_GROUP(1, 0, 3) PIPE_MMA_GROUP(1, 1, 2) PIPE_MMA_GROUP(1, 2, 1) PIPE_MMA_GROUP(1, 3, 0)
+#undef PIPE_MMA_GROUP
+    } else {                      // small-M side-path GEMMs: pixel tiles past M cost nothing (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
+      for (int sub = 0; sub < 2; ++sub) {
+        const int c = sub * 4 + lq;
+        chunk16 wf[TN];
 #pragma unroll
-          for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
-      } else {                    // small-M side-path GEMMs: pixel tiles past M cost nothing (wave-uniform)
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wsm + lds_off(wn * 64 + i * 16 + lr, c));
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           if (j < jmax) {
@@ -152,35 +172,22 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
       }
     }
   }
-  // ---- epilogue, staged through LDS so that HBM sees whole 16-byte chunks of whole rows (igemm_epilogue.h) ----
-  __builtin_amdgcn_s_barrier();                      // every wave is done reading the operand stages
-  constexpr int OLD = BN + 4;                        // staging row in floats, +16 B so ds_write_b128 groups spread over banks
-  float* otile = reinterpret_cast<float*>(smem);
-  const bool geglu = a.act == DC_ACT_GEGLU;
-  const int cout_out = geglu ? (a.Cout >> 1) : a.Cout;
-  const int tcols = geglu ? BN / 2 : BN;
-  int samp[TM];
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
+  // ---- epilogue: straight from the accumulators (igemm_epilogue.h), no LDS, no barrier ----
+  const int mw0 = tile_m * BM + wm * 64;
+  epi_direct<T, TM>(a, acc, tile_n, wn, lq, min(mw0, a.M - 1) / HWo, min(mw0 + 63, a.M - 1) / HWo, [&](int j, EpiRow& r) {
     const int m = tile_m * BM + wm * 64 + j * 16 + lr;
-    samp[j] = (m < a.M ? m : 0) / HWo;
-  }
-  epi_stage<TM, TN>(a, acc, otile, OLD, wm * 64, wn * 64, tile_n * BN + wn * 64, samp, lr, lq);
-  __syncthreads();
-  epi_store(a, otile, OLD, BM, tcols, tile_n * tcols, cout_out, [&](int rloc, size_t& orow, size_t& rrow) {
-    const int m = tile_m * BM + rloc;
-    if (m >= a.M) return false;
-    orow = (size_t)m;
-    rrow = (size_t)m;
-    if (a.residual && a.res_map) { const int n = m / HWo; rrow = (size_t)a.res_map[n] * HWo + (m - n * HWo); }
-    return true;
+    r.ok = m < a.M;
+    const int mm = r.ok ? m : a.M - 1;
+    const int n = mm / HWo;
+    r.samp = n;
+    r.o = mm;
+    r.r = (a.residual && a.res_map) ? a.res_map[n] * HWo + (mm - n * HWo) : mm;
   });
 }
 
 template <typename T, int BM, int S>
 static int launch_pipe(const IgemmArgs& a0, hipStream_t s) {
-  constexpr int lds_main = S * (BM + 128) * 128, lds_epi = BM * (128 + 4) * 4;
-  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;   // 144 KiB (BM 256, S 3) / 66 KiB (BM 128, S 2)
+  constexpr int lds = S * (BM + 128) * 128;                        // 144 KiB (BM 256, S 3) / 64 KiB (BM 128, S 2)
   static bool attr_done = false;
   auto kern = igemm_pipe_kernel<T, BM, S>;
   if (!attr_done) {

@@ -1,0 +1,186 @@
+// igemm_xreg.hip — activation-stationary GEMM for the short-K linear layers (K <= 256, 16-bit): the 1x1
+// shortcuts and every projection of the 16x16 transformer blocks (q/k/v, attention out, proj_in/out, GEGLU).
+//
+// Why: with K = 256 the pipelined tile kernel (igemm_pipe.hip) spends a tile's life in prologue / drain — four
+// K-steps cannot hide the HBM latency of the activation rows, and every N tile re-fetches them (measured
+// 310-370 TFLOP/s, 13 us per 128x128 tile against 1 us of MFMA work).  Here a workgroup owns 96 pixel rows for
+// the WHOLE output width:
+//   * the activation rows are read from HBM exactly once, straight into registers as MFMA B-operand fragments
+//     (3 pixel fragments x K/32 chunks per wave: 96 VGPRs at K = 256) and stay there;
+//   * the weight matrix (<= 1 MiB, L2 resident) streams through a 4-slot LDS ring of 128 couts x 64 k slices by
+//     LDS-DMA, prefetch distance 3 slices, one s_barrier per slice; the stream never drains between N tiles;
+//   * per N tile a wave (48 rows x 64 couts) reads 4 weight fragments per 12 MFMAs — a third of the LDS traffic of
+//     the tile kernel — and finishes with the lane-resident epilogue (igemm_epilogue.h) while the next tile's
+//     weight slices are already landing.  Two workgroups per CU, so one's epilogue overlaps the other's MFMAs.
+//
+// vmcnt bookkeeping: LDS-DMA groups are waited for with counted vmcnt; the epilogue's stores share that counter,
+// so the wave drains its own DMA (vmcnt 0) BEFORE an epilogue and remembers how many slices are known to have
+// landed — the next PD slices need no wait, and by the time one is needed the stores are three slices old.
+#include <stdlib.h>
+#include "igemm_epilogue.h"
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+namespace {
+constexpr int XR_BM = 96;            // pixel rows per workgroup (2 waves x 48)
+constexpr int XR_TM = 3, XR_TN = 4;  // wave tile: 3 pixel fragments x 4 cout fragments
+constexpr int XR_KC = 8;             // K / 32 at most
+constexpr int XR_R = 4, XR_PD = 3;   // weight ring slots, prefetch distance (slices of 64 k)
+constexpr int XR_SLICE = 128 * 128;  // bytes per slice: 128 couts x 64 k x 2 B
+constexpr int XR_WL = 4;             // LDS-DMA instructions per lane per slice (256 lanes x 16 B x 4 = 16 KiB)
+}
+
+template <int N> static __device__ __forceinline__ void xr_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// GEGLU: one kernel per epilogue variant — the activations are live across the epilogue, and two variants inside one
+// kernel pushed hipcc into spilling them
+template <typename T, bool GEGLU>
+__global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit operands only");
+  constexpr int TM = XR_TM, TN = XR_TN, KC = XR_KC, R = XR_R, PD = XR_PD, WL = XR_WL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int tile_m = blockIdx.x;
+  const int HWo = a.Hout * a.Wout;
+  const int kcn = a.Ktot >> 5;                 // 32-element chunks of K
+  const int c0c = a.C0 >> 5;
+  const int spn = a.Ktot >> 6;                 // slices per N tile
+  const int Q = a.tiles_n * spn;               // slices of the whole weight matrix
+
+  // ---- weight loader (LDS image of a slice = the W stage of igemm_pipe.hip: 128-B rows, lds_off swizzle) ----
+  const int lrow = t >> 3;
+  const int lchunk = (t & 7) ^ ((t >> 4) & 7);
+  constexpr bool geglu = GEGLU;
+  int wro[WL];
+#pragma unroll
+  for (int i = 0; i < WL; ++i) wro[i] = epi_wrow(lrow + 32 * i, geglu) * a.Ktot + lchunk * 8;
+  const T* const Wg = reinterpret_cast<const T*>(a.W);
+  int iq = 0, i_nt = 0, i_ks = 0;              // next slice to issue: index, N tile, slice inside the tile
+  auto issue = [&]() {
+    const T* wp = Wg + (size_t)i_nt * 128 * a.Ktot + i_ks * 64;
+    char* dst = smem + (iq % R) * XR_SLICE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WL; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wp + wro[i]), (lptr_t)(dst + i * 4096), 16, 0, 0);
+    ++iq;
+    if (++i_ks == spn) { i_ks = 0; ++i_nt; }
+  };
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+    if (iq < Q) issue();
+
+  // ---- the activation rows of this wave, once, as B-operand fragments: lane (lr, lq) holds k = 32 kc + 8 lq .. +7 of row lr ----
+  chunk16 xr[TM][KC];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = tile_m * XR_BM + wm * 48 + j * 16 + lr;
+    const int mm = m < a.M ? m : a.M - 1;      // rows past M compute garbage-free duplicates, never stored
+    const int n = mm / HWo, pix = mm - n * HWo;
+    const T* b0 = reinterpret_cast<const T*>(a.src0) + ((size_t)(a.map0 ? a.map0[n] : n) * HWo + pix) * a.ld0 + lq * 8;
+    const T* b1 = a.src1 ? reinterpret_cast<const T*>(a.src1) + ((size_t)(a.map1 ? a.map1[n] : n) * HWo + pix) * a.ld1 + lq * 8 : b0;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      xr[j][kc] = chunk16{0u, 0u, 0u, 0u};
+      if (kc < kcn) xr[j][kc] = *reinterpret_cast<const chunk16*>(kc < c0c ? b0 + kc * 32 : b1 + (kc - c0c) * 32);
+    }
+  }
+  // consume the loads HERE: a load still pending at the loop head would make hipcc wait vmcnt(0) in every iteration
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(xr[j][kc]));
+  int landed = iq;                             // that wait also covered the prologue's weight slices
+
+  const uint32_t sbase = lds_addr_of(smem);
+  uint32_t woff[2];                            // fragment read offsets of sub-chunk 0 / 1 (cout fragment i adds i * 2048)
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) woff[sub] = sbase + lds_off(wn * 64 + lr, sub * 4 + lq);
+
+  int q = 0;
+  for (int nt = 0; nt < a.tiles_n; ++nt) {
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KC / 2; ++ks) {
+      if (ks < spn) {
+        if (q >= landed) {                     // my pieces of slice q; younger groups that may stay in flight: min(PD-1, Q-1-q)
+          const int young = Q - 1 - q;
+          if (young >= 2) xr_wait_vmcnt<2 * WL>();
+          else if (young == 1) xr_wait_vmcnt<WL>();
+          else xr_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();          // everyone's pieces are in; everyone is done with slice q-1 (its slot is refilled next)
+        if (iq < Q) issue();
+        const uint32_t sl = (q % R) * XR_SLICE;
+        chunk16 wf[2][TN];
+        lgkm_fence0();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int i = 0; i < TN; ++i) wf[sub][i] = ds_read16_async(woff[sub] + sl + i * 2048);
+#define XR_MMA(SUB, I, NLEFT)                                                                        \
+        lgkm_wait<NLEFT>(wf[SUB][I]);                                                                \
+        _Pragma("unroll") for (int j = 0; j < TM; ++j) acc[I][j] = Mma<T>::run(wf[SUB][I], xr[j][2 * ks + SUB], acc[I][j]); \
+        __builtin_amdgcn_sched_barrier(0);
+        XR_MMA(0, 0, 7) XR_MMA(0, 1, 6) XR_MMA(0, 2, 5) XR_MMA(0, 3, 4)
+        XR_MMA(1, 0, 3) XR_MMA(1, 1, 2) XR_MMA(1, 2, 1) XR_MMA(1, 3, 0)
+#undef XR_MMA
+        ++q;
+      }
+    }
+    // drain my own LDS-DMA before the epilogue's stores join the counter: the next iq - q slices are then known to be in
+    xr_wait_vmcnt<0>();
+    landed = iq;
+    auto rowfn = [&](int j, EpiRow& r) {
+      const int m = tile_m * XR_BM + wm * 48 + j * 16 + lr;
+      r.ok = m < a.M;
+      const int mm = r.ok ? m : a.M - 1;
+      const int n = mm / HWo;
+      r.samp = n;
+      r.o = mm;
+      r.r = (a.residual && a.res_map) ? a.res_map[n] * HWo + (mm - n * HWo) : mm;
+    };
+    const int mw0 = tile_m * XR_BM + wm * 48;
+    const int sf = min(mw0, a.M - 1) / HWo, sl_ = min(mw0 + 47, a.M - 1) / HWo;
+    // SiLU / tanh-GELU / gated outputs stay on igemm_pipe.hip
+    epi_direct_act<T, TM, GEGLU ? DC_ACT_GEGLU : DC_ACT_NONE, false, true>(a, acc, nt, wn, lq, sf, sl_, rowfn);
+  }
+}
+
+bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype) {
+  static const bool off = getenv("DCAMD_NO_XREG") != nullptr;
+  if (off || dtype == DC_F32 || a.taps != 1 || a.gate) return false;
+  if (a.act != DC_ACT_NONE && a.act != DC_ACT_GEGLU) return false;
+  if (a.rowvec && a.Hout * a.Wout < 48) return false;     // a wave's 48 rows must not span more than two samples
+  // pays when the activation rows are reused across N tiles (measured: N = 2048 605 vs 317 TFLOP/s, N = 768 549 vs 333;
+  // N = 256 equal, N = 128 slower than the tile kernel, whose two short tiles per CU overlap better)
+  static const int min_tiles = getenv("DCAMD_XREG_MIN_TILES") ? atoi(getenv("DCAMD_XREG_MIN_TILES")) : 3;
+  if (a.tiles_n < min_tiles) return false;
+  if (a.Ktot > 256 || (a.Ktot & 63) || (a.C0 & 31) || (a.C1 & 31)) return false;
+  return true;
+}
+
+int dc_igemm_xreg_launch(const IgemmArgs& a0, int dtype, hipStream_t s) {
+  constexpr int lds = XR_R * XR_SLICE;          // 64 KiB: two workgroups per CU
+  IgemmArgs a = a0;
+  a.tiles_m = (a.M + XR_BM - 1) / XR_BM;
+  static bool attr_done[4] = {false, false, false, false};
+  const bool gg = a.act == DC_ACT_GEGLU;
+  const int which = (dtype == DC_BF16 ? 0 : 1) + (gg ? 2 : 0);
+  void (*kern)(const IgemmArgs) = dtype == DC_BF16 ? (gg ? igemm_xreg_kernel<__bf16, true> : igemm_xreg_kernel<__bf16, false>)
+                                                   : (gg ? igemm_xreg_kernel<_Float16, true> : igemm_xreg_kernel<_Float16, false>);
+  if (!attr_done[which]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done[which] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_m), dim3(256), lds, s, a);
+  return dc_check_launch("dc_igemm(xreg)");
+}

@@ -24,6 +24,17 @@ SHAPES = {
     "c4_1024_512": (1020, 4, 4, 1024, 512, 9, False),
     "p32_256_128": (1020, 32, 32, 256, 128, 1, False),
     "g64_256_2048": (1020, 64, 1, 256, 2048, 1, False),
+    # transformer-block GEMMs of cfg2 at the production micro-batch (4000 units): name -> (..., act)
+    "geglu16": (4000, 16, 16, 256, 2048, 1, False, "geglu"),
+    "lin16_2048": (4000, 16, 16, 256, 2048, 1, False),
+    "lin16_1024": (4000, 16, 16, 256, 1024, 1, False),
+    "qkv16": (4000, 16, 16, 256, 768, 1, False),
+    "out16": (4000, 16, 16, 256, 256, 1, True),
+    "ffo16": (4000, 16, 16, 1024, 256, 1, True),
+    "geglu8": (4000, 8, 8, 512, 4096, 1, False, "geglu"),
+    "qkv8": (4000, 8, 8, 512, 1536, 1, False),
+    "ffo8": (4000, 8, 8, 2048, 512, 1, True),
+    "short32": (4000, 32, 32, 256, 128, 1, False),
 }
 
 
@@ -38,17 +49,20 @@ def main():
     lib = L.require_gpu()
     dev = "cuda:0"
     for name in args.shapes.split(","):
-        n, H, W, Ci, Co, taps, res = SHAPES[name]
+        n, H, W, Ci, Co, taps, res = SHAPES[name][:7]
+        act = SHAPES[name][7] if len(SHAPES[name]) > 7 else None
+        Cout_out = Co // 2 if act == "geglu" else Co
         x = torch.randn(n, H, W, Ci, device=dev).to(td)
         w = torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5) if taps == 9 else torch.randn(Co, Ci) / Ci ** 0.5
         Wp = E.pack_conv3x3(w, dt, dev) if taps == 9 else E.pack_matrix(w, dt, dev)
         b = torch.randn(Co, device=dev)
-        r = torch.randn(n, H, W, Co, device=dev).to(td) if res else None
-        out = torch.empty(n, H, W, Co, device=dev, dtype=td)
+        r = torch.randn(n, H, W, Cout_out, device=dev).to(td) if res else None
+        out = torch.empty(n, H, W, Cout_out, device=dev, dtype=td)
         p = L.IgemmParams(dtype=dt, taps=taps, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W,
                           src0=x.data_ptr(), C0=Ci, W=Wp.data_ptr(), Cout=Co, tile_n=128, bias=b.data_ptr(),
-                          residual=r.data_ptr() if res else None, res_dtype=dt, res_ld=Co,
-                          out=out.data_ptr(), out_dtype=dt, out_ld=Co)
+                          residual=r.data_ptr() if res else None, res_dtype=dt, res_ld=Cout_out,
+                          act=L.ACT_GEGLU if act == "geglu" else L.ACT_NONE,
+                          out=out.data_ptr(), out_dtype=dt, out_ld=Cout_out)
         for _ in range(3):
             L.check(lib.dc_igemm(p, L.stream_ptr()))
         torch.cuda.synchronize()
@@ -60,7 +74,9 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         fl = 2.0 * n * H * W * Ci * taps * Co
-        print(f"{name:14s} M={n * H * W:8d} N={Co:5d} K={Ci * taps:5d}  {ms:8.4f} ms  {fl / ms / 1e9:7.1f} TF", flush=True)
+        gb = (n * H * W * (Ci + Cout_out * (2 if res else 1))) * x.element_size() / 1e9
+        var = lib.dc_igemm_variant(p).decode() if hasattr(lib, "dc_igemm_variant") else ""
+        print(f"{name:14s} M={n * H * W:8d} N={Co:5d} K={Ci * taps:5d}  {ms:8.4f} ms  {fl / ms / 1e9:7.1f} TF  {gb / ms * 1e3:7.0f} GB/s  {var}", flush=True)
 
 
 if __name__ == "__main__":

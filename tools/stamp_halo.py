@@ -24,7 +24,7 @@ o = torch.empty(n, H, W, Co, device="cuda", dtype=torch.bfloat16)
 p = L.IgemmParams(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=x.data_ptr(), C0=Ci,
                   W=Wp.data_ptr(), Cout=Co, tile_n=128, bias=b.data_ptr(), residual=r.data_ptr() if r is not None else None,
                   res_dtype=dt, res_ld=Co, out=o.data_ptr(), out_dtype=dt, out_ld=Co)
-nblk = n * H * W // 512
+nblk = n * H * W // (256 if H > 8 else 512)
 st = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
 lib.dc_debug_set_stamps.argtypes = [ctypes.c_void_p]
 for _ in range(2):
@@ -34,9 +34,12 @@ lib.dc_debug_set_stamps(st.data_ptr())
 L.check(lib.dc_igemm(p, L.stream_ptr()))
 torch.cuda.synchronize()
 s = st.view(nblk, 8).cpu().double()
-names = ["setup", "mainloop", "bar0", "phase1_a", "phase2_a", "phase1_b", "phase2_b"]
+names = ["setup", "mainloop", "epi:bias", "epi:loads0", "epi:math+batch1", "epi:stores"]
+s = s[:, [0, 1, 2, 3, 4, 5, 7]]
 d = s[:, 1:] - s[:, :-1]
 print("cycles (100MHz s_memtime ticks) per block, median:")
 for i, nm in enumerate(names):
     print(f"  {nm:10s} {d[:, i].median().item():10.0f}")
-print("  total      ", (s[:, 7] - s[:, 0]).median().item())
+print("  total      ", (s[:, 6] - s[:, 0]).median().item())
+t0 = s[:, 0].min().item()
+print("  kernel span", (s[:, 6].max().item() - t0), "ticks;  blocks", nblk, " blocks per CU-slot (512):", nblk / 512)
