@@ -59,7 +59,8 @@ template <int NW> struct HaloCfg {
   static constexpr int WR = NW == 4 ? 3 : 4;            // W ring stages (prefetch distance WR-1 taps); 3 keeps NW=4 at 72 KiB -> 2 per CU
   static constexpr int GNOFF = 2 * XBUF + WR * HALO_WST; // fused-GroupNorm affine of the workgroup's sample: scale[C], shift[C]
   static constexpr int GNMAXC = 512;
-  static constexpr int LDS_MAIN = GNOFF + 2 * GNMAXC * 4;
+  static constexpr int TBLOFF = GNOFF + 2 * GNMAXC * 4;  // per-image sample bases of the two sources: int [ni <= 8][2]
+  static constexpr int LDS_MAIN = TBLOFF + 64;
   static constexpr int LDS = LDS_MAIN;
 };
 
@@ -71,7 +72,10 @@ __device__ __forceinline__ int lds64_off(int row, int chunk) { return row * 64 +
 
 template <int N> __device__ __forceinline__ void hwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int NW>
+template <int V> struct IC { static constexpr int value = V; };
+
+// GN: fused GroupNorm(+SiLU) prologue compiled in (opt-in variant; the plain kernel carries none of its code)
+template <typename T, int NW, bool GN>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
   using Cfg = HaloCfg<NW>;
   constexpr int EPC = Elem<T>::EPC;
@@ -99,31 +103,35 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 
   // ---- X loader: lane fetches LDS position p = i*NT + t  -> halo row p>>2, chunk p&3 (image is not swizzled) ----
   constexpr int NXL = Cfg::NXL;
-  int prow0[NXL], prow1[NXL];                   // source pixel row (sample*H*W + y*W + x) per source, -1 = zero page
+  // per piece: (image of the patch << 20) | pixel offset inside the sample, -1 = padding (zero page); the sample bases
+  // (map lookups) live in a small LDS table, so the loader keeps ONE register per piece whatever the source count
+  int pp[NXL];
   const int xlx = t & 3;
+  int* const tbl = reinterpret_cast<int*>(smem + Cfg::TBLOFF);
+  if (t < (1 << g.lni)) {
+    const int n = (ng << g.lni) + t;
+    const bool vn = n < g.n_img;
+    tbl[2 * t] = vn ? (a.map0 ? a.map0[n] : n) * HW : -1;
+    tbl[2 * t + 1] = (vn && a.src1) ? (a.map1 ? a.map1[n] : n) * HW : -1;
+  }
 #pragma unroll
   for (int i = 0; i < NXL; ++i) {
     const int hr = (i * NT + t) >> 2;
-    prow0[i] = -1; prow1[i] = -1;
+    pp[i] = -1;
     if (i < g.nxl && hr < g.HR) {
       const int img = hr / g.hp, r = hr - img * g.hp;
       const int hy = r / g.hw, hx = r - hy * g.hw;
       const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
-      const int n = (ng << g.lni) + img;
-      if (n < g.n_img && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
-        const int pix = iy * g.W + ix;
-        prow0[i] = (a.map0 ? a.map0[n] : n) * HW + pix;
-        if (a.src1) prow1[i] = (a.map1 ? a.map1[n] : n) * HW + pix;
-      }
+      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) pp[i] = (img << 20) | (iy * g.W + ix);
     }
-    asm volatile("" ::"v"(prow0[i]), "v"(prow1[i]));   // consume the map loads before the LDS-DMA loop
   }
+  __syncthreads();
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (t & 3) * 16;
 
   // ---- fused GroupNorm(+SiLU) prologue: y = act(x*scale[n][c] + shift[n][c]) applied IN PLACE on the landed halo ----
   // (one sample per workgroup; every lane transforms exactly the 16-byte chunks it fetched, and skips padding rows,
   //  which must stay 0 because the reference pads the NORMALISED tensor)
-  const bool gn = a.gn_scale != nullptr;
+  constexpr bool gn = GN;
   float* const gnp = reinterpret_cast<float*>(smem + Cfg::GNOFF);
   if (gn) {
     const int n0 = ng << g.lni;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     __syncthreads();
   }
   auto xform = [&](int ccx, int i) {
-    if (i < g.nxl && prow0[i] >= 0) {
+    if (i < g.nxl && pp[i] >= 0 && tbl[2 * (pp[i] >> 20)] >= 0) {
       chunk16* p = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (i * NT + t) * 16);
       float f[EPC];
       chunk_to_f<T>(*p, f);
@@ -162,12 +170,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     char* xs = smem + (cc & 1) * Cfg::XBUF + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      if (i < g.nxl) {
-        const int pr = s1 ? prow1[i] : prow0[i];
-        const size_t e = (size_t)(pr < 0 ? 0 : pr) * ld + coff;
-        const char* gp = pr < 0 ? zero : reinterpret_cast<const char*>(src + e);
-        __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
-      }
+      // always NXL instructions (pieces past the halo fetch the zero page into the unused tail of the buffer):
+      // the counted vmcnt waits of the tap loop are then compile-time constants
+      const int base = pp[i] < 0 ? -1 : tbl[2 * (pp[i] >> 20) + (s1 ? 1 : 0)];
+      const size_t e = (size_t)(base < 0 ? 0 : base + (pp[i] & 0xFFFFF)) * ld + coff;
+      const char* gp = base < 0 ? zero : reinterpret_cast<const char*>(src + e);
+      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
     }
   };
   // ---- W loader: 128 couts x 64 B per (chunk, tap): position i*NT + t -> row >>2, phys chunk &3 (swizzled) ----
@@ -177,25 +185,26 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     const int row = (i * NT + t) >> 2;
     wrow[i] = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128 + epi_wrow(row, false)) * a.Ktot + ((t & 3) ^ swz64(row)) * EPC;
   }
-  auto issue_w = [&](int s) {                       // s = cc*9 + tap
-    const int cc = s / 9, tap = s - cc * 9;
+  auto issue_w = [&](int cc, int tap, int slot) {
     const size_t koff = (size_t)tap * Ctot + (size_t)cc * BKE;
 #pragma unroll
     for (int i = 0; i < WLD; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wrow[i] + koff),
-                                       (lptr_t)(Wring + (s % WR) * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
+                                       (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
   };
 
-  // ---- per-lane constant byte offsets of the fragment reads ----
-  int xoff[TM], woff[TN];
+  // ---- fragment read addresses: per-lane part (one register each) + wave-uniform part per fragment (SGPRs) ----
+  // pixel p = wm*128 + j*16 + lr: the lr bits never carry into the bit fields set by j (tile widths are >= 8 and a
+  // power of two), so the halo offset splits into f(lr, lq) + f(j); cout fragment i is 16 rows = 1024 B further.
+  const int xl = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64 + lq * 16;
+  int joff[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const int p = wm * 128 + j * 16 + lr;
+    const int p = wm * 128 + j * 16;
     const int img = p >> (g.ltw + g.lth), py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
-    xoff[j] = (img * g.hp + py * g.hw + px) * 64 + lq * 16;
+    joff[j] = __builtin_amdgcn_readfirstlane((img * g.hp + py * g.hw + px) * 64);
   }
-#pragma unroll
-  for (int i = 0; i < TN; ++i) woff[i] = lds64_off(wn * 64 + i * 16 + lr, lq);
+  const int woff0 = lds64_off(wn * 64 + lr, lq);
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -203,63 +212,62 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int NS = nchunks * 9;
   DC_STAMP(1);
+  // ---- tap loop: the 9 taps of a channel chunk are unrolled, so tap offsets, ring slots and every counted vmcnt
+  // are compile-time constants (the rolled loop spent ~300 cycles of scalar control per 512-cycle MFMA block).
+  // W(s) sits in ring slot s % WR, prefetch distance PD; X(cc+1) is issued at tap 0 behind W(s+PD). ----
   issue_x(0);
 #pragma unroll
-  for (int i = 0; i < PD; ++i) issue_w(i);           // NS >= 9 always
+  for (int i = 0; i < PD; ++i) issue_w(0, i, i);     // a chunk has 9 taps >= PD
   if (gn) {                                          // chunk 0: transform before the first tap
     hwait_vmcnt<PD * WLD>();                         // own X(0) loads have landed (the W groups may stay in flight)
 #pragma unroll
     for (int i = 0; i < NXL; ++i) xform(0, i);
   }
-  int tap = 0, cc = 0;
-  for (int s = 0; s < NS; ++s) {
-    // W(s) (and X(cc) when tap == 0) must have landed; younger LDS-DMA groups that may stay in flight:
-    // W(s+1), W(s+2) (WLD instructions each) and, for tap in {1,2,3}, the nxl loads of X(cc+1) issued at tap 0.
-    const int rem = NS - 1 - s;
-    constexpr int FLY = (PD - 1) * WLD;               // W(s+1) .. W(s+PD-1)
-    if (rem >= PD - 1) {
-      const bool xfly = (tap >= 1 && tap <= PD) && (cc + 1 < nchunks);
-      if (!xfly) hwait_vmcnt<FLY>();
-      else if (g.nxl == 3) hwait_vmcnt<FLY + 3>();
-      else if (g.nxl == 4) hwait_vmcnt<FLY + 4>();
-      else if (g.nxl == 5) hwait_vmcnt<FLY + 5>();
-      else if (g.nxl == 6) hwait_vmcnt<FLY + 6>();
-      else if (g.nxl == 7) hwait_vmcnt<FLY + 7>();
-      else hwait_vmcnt<FLY>();
-    } else if (rem == 1) hwait_vmcnt<WLD>();
-    else hwait_vmcnt<0>();
-    if (gn && tap == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my in-place writes of this chunk are in LDS
-    __builtin_amdgcn_s_barrier();
-    if (s + PD < NS) issue_w(s + PD);
-    if (tap == 0 && cc + 1 < nchunks) issue_x(cc + 1);
-
+  constexpr int FLY = (PD - 1) * WLD;                // W(s+1) .. W(s+PD-1)
+  for (int cc = 0; cc < nchunks; ++cc) {
+    const bool has_next = cc + 1 < nchunks;
+    const int s0 = cc * 9;
     const char* Xb = smem + (cc & 1) * Cfg::XBUF;
-    const char* Wst = Wring + (s % WR) * HALO_WST;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int tapoff = (ky * g.hw + kx) * 64;
-    chunk16 xf[TM], wf[TN];
-    // W fragments first, then X; MFMAs in j-major order.  (Issuing all 12 reads asynchronously with counted lgkmcnt
-    // waits — as igemm_pipe.hip does — measured no faster here and costs ~20 VGPRs this kernel does not have: the
-    // second workgroup on the CU already fills the matrix pipe while this wave waits for a fragment.)
+    auto step = [&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      // W(s) (and X(cc) when tap == 0) must have landed.  Younger LDS-DMA groups that may stay in flight: W(s+1) ..
+      // W(s+PD-1) and, for tap in 1..PD, the NXL loads of X(cc+1) issued at tap 0; the last chunk has fewer W groups left.
+      if (has_next) {
+        if (tap >= 1 && tap <= PD) hwait_vmcnt<FLY + NXL>();
+        else hwait_vmcnt<FLY>();
+      } else {
+        constexpr int left = 8 - tap;               // W groups behind this one
+        hwait_vmcnt<(left < PD - 1 ? left : PD - 1) * WLD>();
+      }
+      if (gn && tap == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my in-place writes of this chunk are in LDS
+      __builtin_amdgcn_s_barrier();
+      constexpr int t2 = tap + PD;                    // the W group to issue now: s + PD
+      if (t2 < 9) issue_w(cc, t2, (s0 + t2) % WR);
+      else if (has_next) issue_w(cc + 1, t2 - 9, (s0 + t2) % WR);
+      if (tap == 0 && has_next) issue_x(cc + 1);
+
+      const char* Wst = Wring + ((s0 + tap) % WR) * HALO_WST;
+      constexpr int ky = tap / 3, kx = tap - ky * 3;
+      const int tapoff = (ky * g.hw + kx) * 64;
+      chunk16 xf[TM], wf[TN];
+      // W fragments first, then X; MFMAs in j-major order.  (Issuing all 12 reads asynchronously with counted lgkmcnt
+      // waits — as igemm_pipe.hip does — measured no faster here: the second workgroup on the CU already fills the
+      // matrix pipe while this wave waits for a fragment.)
 #pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff[i]);
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff0 + i * 1024);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + tapoff + xoff[j]);
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[j]) + xl);
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+      for (int j = 0; j < TM; ++j)
 #pragma unroll
-      for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
-    // X(cc+1) was issued at tap 0 and this lane's own pieces were waited for at tap PD+1: from then on transform
-    // one piece per tap, behind this tap's MFMAs (other waves read the buffer only after the next chunk's barrier)
-    if (gn && tap > PD && cc + 1 < nchunks) {
-      const int idx = tap - PD - 1;
-#pragma unroll
-      for (int i = 0; i < NXL; ++i)
-        if (i == idx) xform(cc + 1, i);              // static index: a runtime one would demote prow0[] to scratch
-    }
-    if (++tap == 9) { tap = 0; ++cc; }
+        for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+      // X(cc+1) was issued at tap 0 and this lane's own pieces were waited for at tap PD+1: from then on transform
+      // one piece per tap, behind this tap's MFMAs (other waves read the buffer only after the next chunk's barrier)
+      if (gn && tap > PD && has_next) xform(cc + 1, tap > PD ? tap - PD - 1 : 0);
+    };
+    step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{});
+    step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
   }
 
   DC_STAMP(2);
@@ -311,8 +319,9 @@ bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype) {
 template <typename T, int NW>
 static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s) {
   using Cfg = HaloCfg<NW>;
-  static bool attr_done = false;
-  auto kern = conv3_halo_kernel<T, NW>;
+  static bool attr_done_v[2] = {false, false};
+  bool& attr_done = attr_done_v[a0.gn_scale ? 1 : 0];
+  void (*kern)(const IgemmArgs, const HaloGeom) = a0.gn_scale ? conv3_halo_kernel<T, NW, true> : conv3_halo_kernel<T, NW, false>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_done = true;

@@ -5,6 +5,7 @@
 // norm1/norm3, AdaLayerNormZero) reached through reference nets/unet.py:186 / nets/dit.py:49.
 // HBM-bound: every transfer is a 16-byte chunk per lane, statistics in fp32, deterministic
 // (fixed-order) reductions — no float atomics.
+#include <stdlib.h>
 #include "common.h"
 
 // ------------------------------------------------------------------ GroupNorm -----
@@ -128,6 +129,100 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   }
 }
 
+// One workgroup per sample: statistics sweep, in-block fold, normalise sweep.  The second sweep re-reads the sample
+// while it is still on chip (L2 / Infinity Cache: all resident workgroups together hold ~256 MiB at most), so HBM sees
+// the tensor twice (read, write) instead of three times, and the summation order depends on nothing but (HW, C).
+// Used for samples of up to 1 MiB; larger ones keep the split two-launch scheme above.
+template <typename T>
+__global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int NT = 512, UNR = 4;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][PL][C] partial sums, then mean[groups] / rstd[groups]
+  const int C = a.C0 + a.C1;
+  const int CP = C / EPC, CP0 = a.C0 / EPC;
+  int TPR = 1; while (TPR < CP) TPR <<= 1;                      // CP <= 512 (host check)
+  const int PL = NT / TPR;
+  const int t = threadIdx.x, n = blockIdx.x;
+  const int tc = t % TPR, pl = t / TPR;
+  const bool on = tc < CP;
+  int dummy = 0;
+  const chunk16* src = on ? gn_src<T>(a, n, tc, CP0, 0, dummy) : nullptr;
+  const size_t pstride = (size_t)(tc < CP0 ? a.C0 : a.C1) * sizeof(T) / 16;      // chunks per pixel row of the lane's source
+  float sm[EPC], sq[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+  if (on) {
+    int p = pl;
+    for (; p + (UNR - 1) * PL < a.HW; p += UNR * PL) {
+      chunk16 c[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) c[u] = src[(size_t)(p + u * PL) * pstride];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        float f[EPC];
+        chunk_to_f<T>(c[u], f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+      }
+    }
+    for (; p < a.HW; p += PL) {
+      float f[EPC];
+      chunk_to_f<T>(src[(size_t)p * pstride], f);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+    }
+  }
+  float* rs = red; float* rq = red + PL * C;
+  if (on) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { rs[pl * C + tc * EPC + e] = sm[e]; rq[pl * C + tc * EPC + e] = sq[e]; }
+  }
+  __syncthreads();
+  const int cpg = C / a.groups;
+  float mean_g = 0.f, rstd_g = 0.f;
+  if (t < a.groups) {                                            // groups <= 512 (host check)
+    float S = 0.f, Q = 0.f;
+    for (int l = 0; l < PL; ++l)
+      for (int c = t * cpg; c < (t + 1) * cpg; ++c) { S += rs[l * C + c]; Q += rq[l * C + c]; }
+    const float cnt = (float)cpg * (float)a.HW;
+    mean_g = S / cnt;
+    rstd_g = rsqrtf(fmaxf(Q / cnt - mean_g * mean_g, 0.f) + a.eps);
+  }
+  __syncthreads();
+  if (t < a.groups) { red[t] = mean_g; red[a.groups + t] = rstd_g; }
+  __syncthreads();
+  if (!on) return;
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int ch = tc * EPC + e, g = ch / cpg;
+    const float r = red[a.groups + g] * a.gamma[ch];
+    sc[e] = r; sh[e] = a.beta[ch] - red[g] * r;
+  }
+  chunk16* dst = reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.y) + (size_t)n * a.HW * C) + tc;
+  const size_t ostride = (size_t)C * sizeof(T) / 16;
+  auto norm = [&](const chunk16 cin) {
+    float f[EPC];
+    chunk_to_f<T>(cin, f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float v = f[e] * sc[e] + sh[e];
+      if (a.silu) v = silu_f(v);
+      f[e] = v;
+    }
+    return f_to_chunk<T>(f);
+  };
+  int p = pl;
+  for (; p + (UNR - 1) * PL < a.HW; p += UNR * PL) {
+    chunk16 c[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) c[u] = src[(size_t)(p + u * PL) * pstride];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) dst[(size_t)(p + u * PL) * ostride] = norm(c[u]);
+  }
+  for (; p < a.HW; p += PL) dst[(size_t)p * ostride] = norm(src[(size_t)p * pstride]);
+}
+
 // statistics-only mode: fold the split partials and emit the per-(sample, channel) affine for dc_igemm's fused prologue
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a, float* out_scale, float* out_shift) {
   __shared__ float st[2 * 64];
@@ -199,6 +294,20 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
     else { dc_set_error("dc_groupnorm: dtype %d", p->dtype); return DC_ERR_DTYPE; }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->n), blk, 0, s, a, p->out_scale, p->out_shift);
     return dc_check_launch("dc_groupnorm(stats)");
+  }
+  // samples of up to 1 MiB: one workgroup per sample (gn_image_kernel).  The choice depends on (HW, C) only, never
+  // on n, so a score does not depend on how many samples share a launch.
+  static const bool no_image = getenv("DCAMD_GN_SPLIT") != nullptr;
+  const size_t img_bytes = (size_t)p->HW * C * dc_dtype_size(p->dtype);
+  if (!no_image && img_bytes <= (1u << 20) && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
+    int tpr = 1; while (tpr < CP) tpr <<= 1;
+    const size_t lds_img = (size_t)2 * (512 / tpr) * C * sizeof(float);
+    dim3 g1((unsigned)p->n), b1(512);
+    if (p->dtype == DC_F32) hipLaunchKernelGGL((gn_image_kernel<float>), g1, b1, lds_img, s, a);
+    else if (p->dtype == DC_BF16) hipLaunchKernelGGL((gn_image_kernel<__bf16>), g1, b1, lds_img, s, a);
+    else if (p->dtype == DC_F16) hipLaunchKernelGGL((gn_image_kernel<_Float16>), g1, b1, lds_img, s, a);
+    else { dc_set_error("dc_groupnorm: dtype %d", p->dtype); return DC_ERR_DTYPE; }
+    return dc_check_launch("dc_groupnorm(image)");
   }
   if (p->dtype == DC_F32) {
     hipLaunchKernelGGL((gn_stats_kernel<float>), grid, blk, lds_stats, s, a);
