@@ -49,9 +49,11 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 // group of pixels spent 25-38 k cycles per conv tile exactly there).  Hence three phases: (A) per batch of (up to) four pixel
 // fragments: all loads, then the final fp32 values are formed IN PLACE in the accumulators; (B) only after the last
 // batch: conversions and stores, nothing left to wait for.
-template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn>
+struct EpiNoPre { __device__ __forceinline__ void operator()() const {} };
+
+template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn, typename PreFn = EpiNoPre>
 __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[4][TM], int tile_n, int wn, int lq,
-                                               int samp_first, int samp_last, RowFn rowfn) {
+                                               int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn()) {
   constexpr bool geglu = ACT == DC_ACT_GEGLU;
   constexpr int NK = geglu ? 1 : 2;                  // 8-channel runs per pixel
   constexpr int JB = TM % 4 == 0 ? 4 : TM;           // pixel fragments per load batch
@@ -80,6 +82,7 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     // one row-vector fetch for the wave when its pixels share a sample (samp_first == samp_last, both wave-uniform:
     // a wave's pixels normally lie inside one image)
     const bool uni = samp_first == samp_last;
+    prefn();      // the caller's own waits (igemm_xreg drains its LDS-DMA here) overlap the bias loads issued above
     if (!geglu && a.rowvec && uni) {
 #pragma unroll
       for (int k = 0; k < NK; ++k)

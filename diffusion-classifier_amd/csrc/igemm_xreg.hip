@@ -23,9 +23,8 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 namespace {
-constexpr int XR_BM = 96;            // pixel rows per workgroup (2 waves x 48)
-constexpr int XR_TM = 3, XR_TN = 4;  // wave tile: 3 pixel fragments x 4 cout fragments
-constexpr int XR_KC = 8;             // K / 32 at most
+constexpr int XR_TN = 4;             // cout fragments per wave (64 couts); pixel fragments per wave TM and K/32 chunks KC
+                                     // are template parameters: (3, 8) for K <= 256, (2, 16) for K <= 512
 constexpr int XR_R = 4, XR_PD = 3;   // weight ring slots, prefetch distance (slices of 64 k)
 constexpr int XR_SLICE = 128 * 128;  // bytes per slice: 128 couts x 64 k x 2 B
 constexpr int XR_WL = 4;             // LDS-DMA instructions per lane per slice (256 lanes x 16 B x 4 = 16 KiB)
@@ -35,10 +34,11 @@ template <int N> static __device__ __forceinline__ void xr_wait_vmcnt() { asm vo
 
 // GEGLU: one kernel per epilogue variant — the activations are live across the epilogue, and two variants inside one
 // kernel pushed hipcc into spilling them
-template <typename T, bool GEGLU>
+template <typename T, bool GEGLU, int TM, int KC>
 __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
   static_assert(sizeof(T) == 2, "16-bit operands only");
-  constexpr int TM = XR_TM, TN = XR_TN, KC = XR_KC, R = XR_R, PD = XR_PD, WL = XR_WL;
+  constexpr int TN = XR_TN, R = XR_R, PD = XR_PD, WL = XR_WL;
+  constexpr int WROWS = TM * 16, XR_BM = 2 * WROWS;     // pixel rows per wave / per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
   chunk16 xr[TM][KC];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const int m = tile_m * XR_BM + wm * 48 + j * 16 + lr;
+    const int m = tile_m * XR_BM + wm * WROWS + j * 16 + lr;
     const int mm = m < a.M ? m : a.M - 1;      // rows past M compute garbage-free duplicates, never stored
     const int n = mm / HWo, pix = mm - n * HWo;
     const T* b0 = reinterpret_cast<const T*>(a.src0) + ((size_t)(a.map0 ? a.map0[n] : n) * HWo + pix) * a.ld0 + lq * 8;
@@ -136,11 +136,8 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
         ++q;
       }
     }
-    // drain my own LDS-DMA before the epilogue's stores join the counter: the next iq - q slices are then known to be in
-    xr_wait_vmcnt<0>();
-    landed = iq;
     auto rowfn = [&](int j, EpiRow& r) {
-      const int m = tile_m * XR_BM + wm * 48 + j * 16 + lr;
+      const int m = tile_m * XR_BM + wm * WROWS + j * 16 + lr;
       r.ok = m < a.M;
       const int mm = r.ok ? m : a.M - 1;
       const int n = mm / HWo;
@@ -148,10 +145,15 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
       r.o = mm;
       r.r = (a.residual && a.res_map) ? a.res_map[n] * HWo + (mm - n * HWo) : mm;
     };
-    const int mw0 = tile_m * XR_BM + wm * 48;
-    const int sf = min(mw0, a.M - 1) / HWo, sl_ = min(mw0 + 47, a.M - 1) / HWo;
+    const int mw0 = tile_m * XR_BM + wm * WROWS;
+    const int sf = min(mw0, a.M - 1) / HWo, sl_ = min(mw0 + WROWS - 1, a.M - 1) / HWo;
     // SiLU / tanh-GELU / gated outputs stay on igemm_pipe.hip
-    epi_direct_act<T, TM, GEGLU ? DC_ACT_GEGLU : DC_ACT_NONE, false, true>(a, acc, nt, wn, lq, sf, sl_, rowfn);
+    // the epilogue drains my own LDS-DMA (vmcnt 0) right after issuing its bias / row-vector loads and before its stores
+    // join the counter: the next iq - q slices are then known to be in
+    epi_direct_act<T, TM, GEGLU ? DC_ACT_GEGLU : DC_ACT_NONE, false, true>(a, acc, nt, wn, lq, sf, sl_, rowfn, [&]() {
+      xr_wait_vmcnt<0>();
+      landed = iq;
+    });
   }
 }
 
@@ -159,28 +161,34 @@ bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype) {
   static const bool off = getenv("DCAMD_NO_XREG") != nullptr;
   if (off || dtype == DC_F32 || a.taps != 1 || a.gate) return false;
   if (a.act != DC_ACT_NONE && a.act != DC_ACT_GEGLU) return false;
-  if (a.rowvec && a.Hout * a.Wout < 48) return false;     // a wave's 48 rows must not span more than two samples
+  if (a.rowvec && a.Hout * a.Wout < 48) return false;     // a wave's 48 (32) rows must not span more than two samples
   // pays when the activation rows are reused across N tiles (measured: N = 2048 605 vs 317 TFLOP/s, N = 768 549 vs 333;
   // N = 256 equal, N = 128 slower than the tile kernel, whose two short tiles per CU overlap better)
   static const int min_tiles = getenv("DCAMD_XREG_MIN_TILES") ? atoi(getenv("DCAMD_XREG_MIN_TILES")) : 3;
   if (a.tiles_n < min_tiles) return false;
-  if (a.Ktot > 256 || (a.Ktot & 63) || (a.C0 & 31) || (a.C1 & 31)) return false;
+  if (a.Ktot > 512 || (a.Ktot & 63) || (a.C0 & 31) || (a.C1 & 31)) return false;
   return true;
 }
 
-int dc_igemm_xreg_launch(const IgemmArgs& a0, int dtype, hipStream_t s) {
+template <typename T, int TM, int KC>
+static int xreg_launch_t(const IgemmArgs& a0, hipStream_t s) {
   constexpr int lds = XR_R * XR_SLICE;          // 64 KiB: two workgroups per CU
   IgemmArgs a = a0;
-  a.tiles_m = (a.M + XR_BM - 1) / XR_BM;
-  static bool attr_done[4] = {false, false, false, false};
+  a.tiles_m = (a.M + 2 * TM * 16 - 1) / (2 * TM * 16);
+  static bool attr_done[2] = {false, false};
   const bool gg = a.act == DC_ACT_GEGLU;
-  const int which = (dtype == DC_BF16 ? 0 : 1) + (gg ? 2 : 0);
-  void (*kern)(const IgemmArgs) = dtype == DC_BF16 ? (gg ? igemm_xreg_kernel<__bf16, true> : igemm_xreg_kernel<__bf16, false>)
-                                                   : (gg ? igemm_xreg_kernel<_Float16, true> : igemm_xreg_kernel<_Float16, false>);
-  if (!attr_done[which]) {
+  void (*kern)(const IgemmArgs) = gg ? igemm_xreg_kernel<T, true, TM, KC> : igemm_xreg_kernel<T, false, TM, KC>;
+  if (!attr_done[gg ? 1 : 0]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done[which] = true;
+    attr_done[gg ? 1 : 0] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_m), dim3(256), lds, s, a);
   return dc_check_launch("dc_igemm(xreg)");
+}
+
+int dc_igemm_xreg_launch(const IgemmArgs& a, int dtype, hipStream_t s) {
+  // K <= 256: 96 rows per workgroup (3 fragments x 8 chunks = 96 activation registers per wave);
+  // K <= 512: 64 rows (2 x 16 = 128 registers)
+  if (a.Ktot <= 256) return dtype == DC_BF16 ? xreg_launch_t<__bf16, 3, 8>(a, s) : xreg_launch_t<_Float16, 3, 8>(a, s);
+  return dtype == DC_BF16 ? xreg_launch_t<__bf16, 2, 16>(a, s) : xreg_launch_t<_Float16, 2, 16>(a, s);
 }

@@ -132,6 +132,71 @@ def test_gemm_epilogues(dt, act):
     assert maxrel(out.cpu(), y) < (2e-5 if dt == L.DC_F32 else 2e-3), maxrel(out.cpu(), y)
 
 
+@pytest.mark.parametrize("case", ["k256_res_rowvec", "k256_dual_maps_geglu", "k512_tail_f16_f32out", "k128_many_tiles",
+                                  "tiny_images_rowvec"])
+def test_gemm_activation_stationary(case):
+    """igemm_xreg (K <= 512, 16-bit, >= 3 N tiles): activation rows held in registers across all N tiles.  Cases cover
+    ragged M, two sources with sample maps, residual through a sample map, a row vector whose samples straddle a wave,
+    GEGLU, a channel tail (Cout not a multiple of 128) and an fp32 output; the last one must NOT take the kernel."""
+    torch.manual_seed(11)
+    dt = L.DC_F16 if case == "k512_tail_f16_f32out" else L.DC_BF16
+    td = TD[dt]
+    q = lambda t: t.to(td).float()
+    cfgs = {  # n_out, rows_per (H*W), C0, C1, Nn, act, residual, rowvec, maps, out f32
+        "k256_res_rowvec": (7, 80, 256, 0, 512, L.ACT_NONE, True, True, False, False),
+        "k256_dual_maps_geglu": (6, 64, 128, 128, 768, L.ACT_GEGLU, False, False, True, False),
+        "k512_tail_f16_f32out": (5, 64, 512, 0, 648, L.ACT_NONE, True, False, False, True),
+        "k128_many_tiles": (9, 50, 128, 0, 1024, L.ACT_NONE, False, True, False, False),
+        "tiny_images_rowvec": (40, 16, 256, 0, 512, L.ACT_NONE, False, True, False, False),
+    }
+    n_out, HW, C0, C1, Nn, act, use_res, use_rv, use_maps, out32 = cfgs[case]
+    n_src = 4 if use_maps else n_out
+    x0 = q(torch.randn(n_src, HW, C0))
+    x1 = q(torch.randn(n_src, HW, C1)) if C1 else None
+    m0 = torch.randint(0, n_src, (n_out,), dtype=torch.int32) if use_maps else None
+    m1 = torch.randint(0, n_src, (n_out,), dtype=torch.int32) if (use_maps and C1) else None
+    w = q(torch.randn(Nn, C0 + C1) / (C0 + C1) ** 0.5)
+    b = torch.randn(Nn)
+    a0 = x0[m0.long()] if use_maps else x0
+    a = torch.cat([a0, x1[m1.long()] if use_maps else x1], -1) if C1 else a0
+    y = a.reshape(n_out * HW, -1) @ w.t() + b
+    n_ch = Nn
+    if act == L.ACT_GEGLU:
+        u, gg = y.chunk(2, dim=-1)
+        y = u * F.gelu(gg)
+        perm = E.geglu_perm(Nn // 2)
+        Wp, bp, n_ch = E.pack_matrix(w[perm], dt, DEV), b[perm].contiguous().to(DEV), Nn // 2
+    else:
+        Wp, bp = E.pack_matrix(w, dt, DEV), b.to(DEV)
+    rv = rvm = None
+    if use_rv:
+        table = torch.randn(5, n_ch)
+        rvm = torch.randint(0, 5, (n_out,), dtype=torch.int32)
+        y = y + table[rvm.long()].repeat_interleave(HW, 0)
+        rv, rvm = table.to(DEV).contiguous(), rvm.to(DEV)
+    res = resm = None
+    if use_res:
+        rsrc = q(torch.randn(3, HW, n_ch))
+        rm = torch.randint(0, 3, (n_out,), dtype=torch.int32)
+        y = y + rsrc[rm.long()].reshape(n_out * HW, n_ch)
+        res, resm = rsrc.to(td).to(DEV), rm.to(DEV)
+    odt = L.DC_F32 if out32 else dt
+    out = torch.full((n_out * HW, n_ch), float("nan"), dtype=TD[odt], device=DEV)
+    d0, d1 = x0.to(td).to(DEV), (x1.to(td).to(DEV) if C1 else None)
+    md0, md1 = (m0.to(DEV) if use_maps else None), (m1.to(DEV) if m1 is not None else None)
+    kw = dict(dtype=dt, taps=1, stride=1, upsample=0, n_img=n_out, Hin=HW, Win=1, Hout=HW, Wout=1,
+              src0=ptr(d0), map0=ptr(md0), C0=C0, ld0=0, src1=ptr(d1), map1=ptr(md1), C1=C1, ld1=0,
+              W=ptr(Wp), Cout=Nn, tile_n=128, bias=ptr(bp), act=act, rowvec=ptr(rv), rowvec_map=ptr(rvm), rowvec_ld=n_ch,
+              residual=ptr(res), res_map=ptr(resm), res_dtype=dt, res_ld=n_ch, out=ptr(out), out_dtype=odt, out_ld=n_ch)
+    variant = L.lib().dc_igemm_variant(L.IgemmParams(**kw)).decode()
+    assert ("xreg" in variant) == (case != "tiny_images_rowvec"), variant
+    run_igemm(**kw)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    tol = 2e-3 if out32 else TOL[dt]        # fp32 output of 16-bit operands: only the accumulation order differs
+    assert maxrel(got, y) < tol, (case, variant, maxrel(got, y))
+
+
 def test_gemm_strided_source_and_rowvec_map():
     """ld0 > C0 (a column slice of a wider matrix) and an indexed per-sample vector."""
     torch.manual_seed(3)
