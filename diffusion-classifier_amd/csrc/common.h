@@ -68,7 +68,10 @@ __device__ __forceinline__ float erf_as_f(float z) {
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float k = 0.79788456080286535588f;  // sqrt(2/pi)
-  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+  // 0.5 x (1 + tanh u) == x / (1 + exp(-2u)): one exp + one divide instead of ocml tanhf (the DiT fc1 epilogue was
+  // VALU-bound on it); exp(-2u) -> inf / 0 at the tails gives the exact limits -0 / x
+  const float u = k * (x + 0.044715f * x * x * x);
+  return x / (1.0f + expf(-2.0f * u));
 }
 
 // store one value of runtime dtype
@@ -100,6 +103,11 @@ __device__ __forceinline__ chunk16 ds_read16_async(uint32_t addr) {
 }
 // lgkmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt / expcnt fields all ones = no wait): the compiler's own waitcnt
 // bookkeeping sees it, so it does not drop a second lgkmcnt(0) of its own into the middle of the asynchronous reads
+template <int OFF> __device__ __forceinline__ chunk16 ds_read16_async_off(uint32_t addr) {     // addr + OFF (OFF < 65536, immediate)
+  chunk16 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
 __device__ __forceinline__ void lgkm_fence0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 template <int N> __device__ __forceinline__ void lgkm_wait(chunk16& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N> __device__ __forceinline__ void lgkm_wait(chunk16& a, chunk16& b, chunk16& c, chunk16& d, chunk16& e) {

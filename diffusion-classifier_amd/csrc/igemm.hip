@@ -250,7 +250,6 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   const bool use_v1 = env_v1 || !lane_epi_ok;
   static const bool no_halo = getenv("DCAMD_NO_HALO") != nullptr;
   static const int halo_nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
-  static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
   const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
   if (a.gn_scale && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
@@ -262,7 +261,10 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     static thread_local char name[64];
     if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && dc_igemm_xreg_applicable(a, p->dtype)) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
-    else if (bn == 128 && !use_v1) snprintf(name, sizeof(name), a.nk <= light_nk ? "igemm_pipe<%s,128x128,2st>" : "igemm_pipe<%s,256x128,3st>", dn);
+    else if (bn == 128 && !use_v1) {
+      static const char* const shapes[3] = {"igemm_pipe<%s,128x128,2st>", "igemm_pipe<%s,256x128,3st>", "igemm_pipe<%s,256x256,2st>"};
+      snprintf(name, sizeof(name), shapes[dc_igemm_pipe_shape(a)], dn);
+    }
     else snprintf(name, sizeof(name), "igemm<%s,128x%d>", dn, bn);
     *variant = name;
     return DC_OK;

@@ -28,11 +28,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // BM = 256, S = 3: 8 waves, 144 KiB, one workgroup per CU  — long K loops (3x3 convs, big-K GEMMs)
 // BM = 128, S = 2: 4 waves,  66 KiB, two workgroups per CU — short K loops, where the prologue/epilogue of
 //                  one workgroup must overlap the K loop of the other (K <= 512 spends most of a tile there)
-template <typename T, int BM, int S>
+// NH = 2 (BM = 256, S = 2): 256 x 256 tile, each wave 64 pixels x 128 couts — 12 fragment reads per 32 MFMAs instead of
+//                  8 per 16 and a third less LDS-DMA per MFMA (the 64x64 wave tile is LDS-bandwidth bound at ~50 % of
+//                  the matrix pipe); wide layers (Cout a multiple of 256) with long K loops
+// EV: epilogue variant compiled in: -1 = all five behind a wave-uniform switch; 0 = plain, 3 = tanh-GELU, 4 = plain + gate.
+//     The 256x256 kernel holds 128 accumulator registers and is instantiated per variant (several variants in one
+//     kernel pushed hipcc into spilling accumulators inside the K loop).
+// SLIM: 1-tap GEMM — the loader keeps one row pointer per source instead of the tap geometry (gating this at run time
+//       kept the tap state live and cost the GEMMs ~20 %: it is a separate instantiation).
+template <typename T, int BM, int S, int NH, int EV, bool SLIM>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a) {
+  static_assert(NH == 1 || SLIM, "the wide tile takes 1-tap GEMMs only");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKE = 8 * EPC;
-  constexpr int BN = 128;
+  constexpr int BN = 128 * NH;
   constexpr int NT = BM * 2;                 // threads
   constexpr int RPI = NT / 8;                // tile rows covered by one LDS-DMA instruction of the workgroup
   constexpr int WL = BN / RPI;               // W loads per lane per K-step (X loads: BM / RPI == 4)
@@ -81,13 +90,43 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
   const T* wbase = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * BN) * a.Ktot + lchunk * EPC;
   int wro[WL];                                                // element offset of the W row behind LDS row lrow + RPI*i
 #pragma unroll
-  for (int i = 0; i < WL; ++i) wro[i] = epi_wrow(lrow + RPI * i, a.act == DC_ACT_GEGLU) * a.Ktot;
+  for (int i = 0; i < WL; ++i) {
+    const int R = lrow + RPI * i;                             // LDS row: 128-row sub-tile R >> 7, permuted inside it
+    wro[i] = ((R >> 7) * 128 + epi_wrow(R & 127, a.act == DC_ACT_GEGLU)) * a.Ktot;
+  }
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (t & 7) * 16;
   const int Hm1 = a.Hin - 1, Wm1 = a.Win - 1;
 
+  const T* xrow0[4]; const T* xrow1[4];
+  constexpr bool slim = SLIM;
+  if (slim) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool vm = iy0[i] >= 0;
+      xrow0[i] = vm ? base0[i] + (iy0[i] * Ws + ix0[i]) * a.ld0 + lchunk * EPC : nullptr;
+      xrow1[i] = (vm && a.src1) ? base1[i] + (iy0[i] * Ws + ix0[i]) * a.ld1 + lchunk * EPC : nullptr;
+    }
+  }
   int itap = 0, icc = 0;   // (tap, channel chunk) of the next K-step to issue
   auto issue = [&](int ks) {
     const int st = ks % S;
+    if (slim) {
+      const bool s1 = icc >= a.c0chunks;
+      const int coff = (s1 ? icc - a.c0chunks : icc) * BKE;
+      char* xs = smem + st * STAGE + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const T* rp = s1 ? xrow1[i] : xrow0[i];
+        const char* gp = rp ? reinterpret_cast<const char*>(rp + coff) : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
+      }
+      char* ws = smem + st * STAGE + XST + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < WL; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wbase + wro[i] + ks * BKE), (lptr_t)(ws + i * (NT * 16)), 16, 0, 0);
+      ++icc;
+      return;
+    }
     int ky = 0, kx = 0;
     if (a.taps == 9) { ky = itap / 3; kx = itap - ky * 3; }
     const bool s1 = icc >= a.c0chunks;
@@ -117,11 +156,20 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
   // number of 16-row pixel tiles of this wave that contain real rows
   const int rows_left = a.M - (tile_m * BM + wm * 64);
   const int jmax = __builtin_amdgcn_readfirstlane(rows_left <= 0 ? 0 : (rows_left >= 64 ? 4 : (rows_left + 15) >> 4));
-  f32x4 acc[TN][TM];
+  f32x4 acc[NH][TN][TM];                     // [64-cout half of the wave][cout fragment][pixel fragment]
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wrow0 = wn * 64 * NH;            // first LDS weight row of the wave
+  int wfo[2], xfo[2];                        // stage-relative byte offsets of the wave's first W / X fragment, sub-steps 0 / 1
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    wfo[sub] = XST + lds_off(wrow0 + lr, sub * 4 + lq);
+    xfo[sub] = lds_off(wm * 64 + lr, sub * 4 + lq);
+  }
 
   issue(0);
   if (S == 3 && a.nk > 1) issue(1);
@@ -132,49 +180,79 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     if (ks + S - 1 < a.nk) issue(ks + S - 1);
     const char* Xs = smem + (ks % S) * STAGE;
     const char* Wsm = Xs + XST;
-    if (jmax == TM) {             // the hot path: every pixel tile of the wave is real
+    if (jmax == TM && NH == 1) {  // the hot path: every pixel tile of the wave is real
       // all 16 fragment reads of the K-step go out first (asynchronous, common.h); the MFMAs follow in groups of
       // four behind counted lgkmcnt waits, so the later fragments arrive under the running matrix pipe
-      const uint32_t xb = lds_addr_of(Xs), wb = lds_addr_of(Wsm);
+      // (fragment i / j is 16 rows = 2048 B further and keeps the row's swizzle: an immediate offset, one address register
+      //  per operand and sub-step)
+      const uint32_t stb = lds_addr_of(Xs);
       chunk16 xf[2][TM], wf[2][TN];
       lgkm_fence0();
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        const int c = sub * 4 + lq;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[sub][i] = ds_read16_async(wb + lds_off(wn * 64 + i * 16 + lr, c));
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[sub][j] = ds_read16_async(xb + lds_off(wm * 64 + j * 16 + lr, c));
+        const uint32_t wa = stb + wfo[sub], xa = stb + xfo[sub];
+        wf[sub][0] = ds_read16_async_off<0>(wa); wf[sub][1] = ds_read16_async_off<2048>(wa);
+        wf[sub][2] = ds_read16_async_off<4096>(wa); wf[sub][3] = ds_read16_async_off<6144>(wa);
+        xf[sub][0] = ds_read16_async_off<0>(xa); xf[sub][1] = ds_read16_async_off<2048>(xa);
+        xf[sub][2] = ds_read16_async_off<4096>(xa); xf[sub][3] = ds_read16_async_off<6144>(xa);
       }
 #define PIPE_MMA_GROUP(SUB, J, NLEFT)                                                     \
       lgkm_wait<NLEFT>(xf[SUB][J]);                                                         \
-      _Pragma("unroll") for (int i = 0; i < TN; ++i) acc[i][J] = Mma<T>::run(wf[SUB][i], xf[SUB][J], acc[i][J]);  \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) acc[0][i][J] = Mma<T>::run(wf[SUB][i], xf[SUB][J], acc[0][i][J]);  \
       __builtin_amdgcn_sched_barrier(0);
       lgkm_wait<11>(wf[0][0], wf[0][1], wf[0][2], wf[0][3], xf[0][0]);
       PIPE_MMA_GROUP(0, 0, 11) PIPE_MMA_GROUP(0, 1, 10) PIPE_MMA_GROUP(0, 2, 9) PIPE_MMA_GROUP(0, 3, 8)
       lgkm_wait<3>(wf[1][0], wf[1][1], wf[1][2], wf[1][3], xf[1][0]);
       PIPE_MMA_GROUP(1, 0, 3) PIPE_MMA_GROUP(1, 1, 2) PIPE_MMA_GROUP(1, 2, 1) PIPE_MMA_GROUP(1, 3, 0)
 #undef PIPE_MMA_GROUP
+    } else if (NH == 2) {         // 256x256 tile: no short-M side path (rows past M read the zero page; big-M layers only)
+      const uint32_t stb = lds_addr_of(Xs);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const uint32_t wa = stb + wfo[sub], xa = stb + xfo[sub];
+        chunk16 xf[TM], wf[TN];
+        lgkm_fence0();
+        wf[0] = ds_read16_async_off<0>(wa); wf[1] = ds_read16_async_off<2048>(wa);
+        wf[2] = ds_read16_async_off<4096>(wa); wf[3] = ds_read16_async_off<6144>(wa);
+        xf[0] = ds_read16_async_off<0>(xa); xf[1] = ds_read16_async_off<2048>(xa);
+        xf[2] = ds_read16_async_off<4096>(xa); xf[3] = ds_read16_async_off<6144>(xa);
+#define PIPE_MMA_GROUP2(H, J, NLEFT)                                                    \
+        lgkm_wait<NLEFT>(xf[J]);                                                          \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) acc[H][i][J] = Mma<T>::run(wf[i], xf[J], acc[H][i][J]);  \
+        __builtin_amdgcn_sched_barrier(0);
+        lgkm_wait<3>(wf[0], wf[1], wf[2], wf[3], xf[0]);
+        PIPE_MMA_GROUP2(0, 0, 3) PIPE_MMA_GROUP2(0, 1, 2) PIPE_MMA_GROUP2(0, 2, 1) PIPE_MMA_GROUP2(0, 3, 0)
+        // second 64-cout half: its four weight fragments reuse the registers of the first (one short exposed LDS
+        // latency per 32-k sub-step, against 16 registers this kernel does not have)
+        wf[0] = ds_read16_async_off<8192>(wa); wf[1] = ds_read16_async_off<10240>(wa);
+        wf[2] = ds_read16_async_off<12288>(wa); wf[3] = ds_read16_async_off<14336>(wa);
+        lgkm_wait<0>(wf[0], wf[1], wf[2], wf[3], xf[0]);
+        PIPE_MMA_GROUP2(NH - 1, 0, 0) PIPE_MMA_GROUP2(NH - 1, 1, 0) PIPE_MMA_GROUP2(NH - 1, 2, 0) PIPE_MMA_GROUP2(NH - 1, 3, 0)
+#undef PIPE_MMA_GROUP2
+      }
     } else {                      // small-M side-path GEMMs: pixel tiles past M cost nothing (wave-uniform)
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const int c = sub * 4 + lq;
-        chunk16 wf[TN];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wsm + lds_off(wn * 64 + i * 16 + lr, c));
+        for (int h = 0; h < NH; ++h) {
+          chunk16 wf[TN];
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          if (j < jmax) {
-            const chunk16 x1 = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
+          for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wsm + lds_off(wrow0 + h * 64 + i * 16 + lr, c));
 #pragma unroll
-            for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], x1, acc[i][j]);
-          }
+          for (int j = 0; j < TM; ++j)
+            if (j < jmax) {
+              const chunk16 x1 = *reinterpret_cast<const chunk16*>(Xs + lds_off(wm * 64 + j * 16 + lr, c));
+#pragma unroll
+              for (int i = 0; i < TN; ++i) acc[h][i][j] = Mma<T>::run(wf[i], x1, acc[h][i][j]);
+            }
+        }
       }
     }
   }
   // ---- epilogue: straight from the accumulators (igemm_epilogue.h), no LDS, no barrier ----
   const int mw0 = tile_m * BM + wm * 64;
-  epi_direct<T, TM>(a, acc, tile_n, wn, lq, min(mw0, a.M - 1) / HWo, min(mw0 + 63, a.M - 1) / HWo, [&](int j, EpiRow& r) {
+  auto rowfn = [&](int j, EpiRow& r) {
     const int m = tile_m * BM + wm * 64 + j * 16 + lr;
     r.ok = m < a.M;
     const int mm = r.ok ? m : a.M - 1;
@@ -182,34 +260,82 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     r.samp = n;
     r.o = mm;
     r.r = (a.residual && a.res_map) ? a.res_map[n] * HWo + (mm - n * HWo) : mm;
-  });
+  };
+  const int sf = min(mw0, a.M - 1) / HWo, sl = min(mw0 + 63, a.M - 1) / HWo;
+  // one 64-cout half of the wave at a time (written out, not looped: a loop index would demote acc[] to scratch):
+  // 128-cout tile index and half inside it
+  auto epi = [&](f32x4 (&ac)[TN][TM], int tile128, int half) {
+    if (EV < 0) epi_direct<T, TM>(a, ac, tile128, half, lq, sf, sl, rowfn);
+    else epi_direct_act<T, TM, (EV == 3 ? DC_ACT_GELU_TANH : DC_ACT_NONE), EV == 4, false>(a, ac, tile128, half, lq, sf, sl, rowfn);
+  };
+  if (NH == 1) epi(acc[0], tile_n, wn);
+  else {
+    epi(acc[0], tile_n * 2 + wn, 0);
+    __builtin_amdgcn_sched_barrier(0);       // keep the second half's loads behind the first half's stores' issue: one epilogue's registers at a time
+    epi(acc[NH - 1], tile_n * 2 + wn, 1);
+  }
 }
 
-template <typename T, int BM, int S>
+template <typename T, int BM, int S, int NH, int EV, bool SLIM>
 static int launch_pipe(const IgemmArgs& a0, hipStream_t s) {
-  constexpr int lds = S * (BM + 128) * 128;                        // 144 KiB (BM 256, S 3) / 64 KiB (BM 128, S 2)
+  constexpr int lds = S * (BM + 128 * NH) * 128;                   // 144 KiB (256x128, S 3) / 64 KiB (128x128, S 2) / 128 KiB (256x256, S 2)
   static bool attr_done = false;
-  auto kern = igemm_pipe_kernel<T, BM, S>;
+  auto kern = igemm_pipe_kernel<T, BM, S, NH, EV, SLIM>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   IgemmArgs a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = a0.tiles_n / NH;                                     // a0.tiles_n counts 128-cout tiles
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("dc_igemm: bad grid %lld", nblk); return DC_ERR_SHAPE; }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BM * 2), lds, s, a);
   return dc_check_launch("dc_igemm(pipe)");
 }
 
-int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s) {
+template <typename T>
+static int launch_wide(const IgemmArgs& a, hipStream_t s) {
+  if (a.act == DC_ACT_GELU_TANH) return launch_pipe<T, 256, 2, 2, 3, true>(a, s);
+  if (a.gate) return launch_pipe<T, 256, 2, 2, 4, true>(a, s);
+  return launch_pipe<T, 256, 2, 2, 0, true>(a, s);
+}
+
+// 0: 128x128 / 2 stages, 1: 256x128 / 3 stages, 2: 256x256 / 2 stages
+int dc_igemm_pipe_shape(const IgemmArgs& a) {
   static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
-  if (a.nk <= light_nk) {
-    if (dtype == DC_BF16) return launch_pipe<__bf16, 128, 2>(a, s);
-    if (dtype == DC_F16) return launch_pipe<_Float16, 128, 2>(a, s);
-    return launch_pipe<float, 128, 2>(a, s);
+  static const bool no_wide = getenv("DCAMD_PIPE_NO_WIDE") != nullptr;
+  static const long long wide_min = getenv("DCAMD_PIPE_WIDE_MIN") ? atoll(getenv("DCAMD_PIPE_WIDE_MIN")) : 256LL * 2 * 512;   // M x (128-cout tiles)
+  if (a.nk <= light_nk) return 0;
+  const bool wide_act = a.act == DC_ACT_NONE || (a.act == DC_ACT_GELU_TANH && !a.gate);     // the variants launch_wide has
+  if (!no_wide && wide_act && a.taps == 1 && (a.tiles_n & 1) == 0 && (long long)a.M * a.tiles_n >= wide_min) return 2;   // wide layer, enough 256x256 tiles to fill the chip
+  return 1;
+}
+
+int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s) {
+  const int shape = dc_igemm_pipe_shape(a);
+  const bool slim = a.taps == 1;
+  if (shape == 0) {
+    if (slim) {
+      if (dtype == DC_BF16) return launch_pipe<__bf16, 128, 2, 1, -1, true>(a, s);
+      if (dtype == DC_F16) return launch_pipe<_Float16, 128, 2, 1, -1, true>(a, s);
+      return launch_pipe<float, 128, 2, 1, -1, true>(a, s);
+    }
+    if (dtype == DC_BF16) return launch_pipe<__bf16, 128, 2, 1, -1, false>(a, s);
+    if (dtype == DC_F16) return launch_pipe<_Float16, 128, 2, 1, -1, false>(a, s);
+    return launch_pipe<float, 128, 2, 1, -1, false>(a, s);
   }
-  if (dtype == DC_BF16) return launch_pipe<__bf16, 256, 3>(a, s);
-  if (dtype == DC_F16) return launch_pipe<_Float16, 256, 3>(a, s);
-  return launch_pipe<float, 256, 3>(a, s);
+  if (shape == 2) {
+    if (dtype == DC_BF16) return launch_wide<__bf16>(a, s);
+    if (dtype == DC_F16) return launch_wide<_Float16>(a, s);
+    return launch_wide<float>(a, s);
+  }
+  if (slim) {
+    if (dtype == DC_BF16) return launch_pipe<__bf16, 256, 3, 1, -1, true>(a, s);
+    if (dtype == DC_F16) return launch_pipe<_Float16, 256, 3, 1, -1, true>(a, s);
+    return launch_pipe<float, 256, 3, 1, -1, true>(a, s);
+  }
+  if (dtype == DC_BF16) return launch_pipe<__bf16, 256, 3, 1, -1, false>(a, s);
+  if (dtype == DC_F16) return launch_pipe<_Float16, 256, 3, 1, -1, false>(a, s);
+  return launch_pipe<float, 256, 3, 1, -1, false>(a, s);
 }

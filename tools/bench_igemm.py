@@ -35,6 +35,11 @@ SHAPES = {
     "qkv8": (4000, 8, 8, 512, 1536, 1, False),
     "ffo8": (4000, 8, 8, 2048, 512, 1, True),
     "short32": (4000, 32, 32, 256, 128, 1, False),
+    # DiT-B/4 GEMMs (1000 units x 1024 tokens)
+    "dit_qkv": (1000, 32, 32, 768, 2304, 1, False),
+    "dit_proj": (1000, 32, 32, 768, 768, 1, True),
+    "dit_fc1": (1000, 32, 32, 768, 3072, 1, False, "gelu_tanh"),
+    "dit_fc2": (1000, 32, 32, 3072, 768, 1, True),
 }
 
 
@@ -61,7 +66,7 @@ def main():
         p = L.IgemmParams(dtype=dt, taps=taps, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W,
                           src0=x.data_ptr(), C0=Ci, W=Wp.data_ptr(), Cout=Co, tile_n=128, bias=b.data_ptr(),
                           residual=r.data_ptr() if res else None, res_dtype=dt, res_ld=Cout_out,
-                          act=L.ACT_GEGLU if act == "geglu" else L.ACT_NONE,
+                          act={"geglu": L.ACT_GEGLU, "gelu_tanh": L.ACT_GELU_TANH}.get(act, L.ACT_NONE),
                           out=out.data_ptr(), out_dtype=dt, out_ld=Cout_out)
         for _ in range(3):
             L.check(lib.dc_igemm(p, L.stream_ptr()))
