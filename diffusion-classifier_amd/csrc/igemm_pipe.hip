@@ -108,6 +108,21 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     }
   }
   int itap = 0, icc = 0;   // (tap, channel chunk) of the next K-step to issue
+  // tap geometry of the loader rows, refreshed when the issue stream moves to the next tap: source pixel index inside
+  // the sample, -1 = padding (zero page).  (Recomputing it in every K-step cost ~20 VALU per row and step.)
+  int pixo[4] = {-1, -1, -1, -1};
+  auto set_tap = [&](int tap) {
+    int ky = 0, kx = 0;
+    if (a.taps == 9) { ky = tap / 3; kx = tap - ky * 3; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      const bool ok = (unsigned)iy <= (unsigned)Hm1 && (unsigned)ix <= (unsigned)Wm1;
+      const int sy = a.upsample ? (iy >> 1) : iy, sx = a.upsample ? (ix >> 1) : ix;
+      pixo[i] = ok ? sy * Ws + sx : -1;
+    }
+  };
+  if (!slim) set_tap(0);
   auto issue = [&](int ks) {
     const int st = ks % S;
     if (slim) {
@@ -127,21 +142,14 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
       ++icc;
       return;
     }
-    int ky = 0, kx = 0;
-    if (a.taps == 9) { ky = itap / 3; kx = itap - ky * 3; }
     const bool s1 = icc >= a.c0chunks;
     const int ld = s1 ? a.ld1 : a.ld0;
     const int coff = (s1 ? icc - a.c0chunks : icc) * BKE + lchunk * EPC;
     char* xs = smem + st * STAGE + wave * 1024;              // wave-uniform LDS base; HW adds lane*16
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-      const bool ok = (unsigned)iy <= (unsigned)Hm1 && (unsigned)ix <= (unsigned)Wm1;
-      const int cy = min(max(iy, 0), Hm1), cx = min(max(ix, 0), Wm1);     // always a real pixel: no branch
-      const int sy = a.upsample ? (cy >> 1) : cy, sx = a.upsample ? (cx >> 1) : cx;
-      const int off = (sy * Ws + sx) * ld + coff;
-      const char* gp = reinterpret_cast<const char*>((s1 ? base1[i] : base0[i]) + off);
-      gp = ok ? gp : zero;
+      const char* gp = reinterpret_cast<const char*>((s1 ? base1[i] : base0[i]) + (pixo[i] < 0 ? 0 : pixo[i]) * ld + coff);
+      gp = pixo[i] < 0 ? zero : gp;
       __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
     }
     char* ws = smem + st * STAGE + XST + wave * 1024;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
       const char* gp = reinterpret_cast<const char*>(wbase + wro[i] + ks * BKE);
       __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(ws + i * (NT * 16)), 16, 0, 0);
     }
-    if (++icc == a.cpt) { icc = 0; ++itap; }
+    if (++icc == a.cpt) { icc = 0; ++itap; set_tap(itap); }   // wave-uniform: once per tap, not per K-step
   };
 
   // number of 16-row pixel tiles of this wave that contain real rows

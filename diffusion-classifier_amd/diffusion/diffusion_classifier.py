@@ -450,24 +450,43 @@ class _HipRunner:
         if host is None or host.shape[0] < n_mb:
             host = sp["host"] = torch.zeros((n_mb, sp["words"]), dtype=torch.int32).pin_memory()
         dump = BS * ncls * T
+        # the index part of every control block (pair ids, image / class / output maps) depends on (pairs, classes) only:
+        # built once and kept (stage 0 of every call sees the same pairs and the full class list); per call only the
+        # three float rows (lambda, alpha, sigma of this call's t draws) are gathered.  Host time here is GPU idle time.
+        ck = (n_bj, len(pairs), pairs[0], pairs[-1], classes.numpy().tobytes())
+        cache = sp.setdefault("idx_cache", {})
+        ent = cache.get(ck)
+        if ent is None:
+            if len(cache) > 8:
+                cache.clear()
+            tmpl = torch.zeros((n_mb, sp["words"]), dtype=torch.int32)
+            jsb = []
+            for m in range(n_mb):
+                chunk = pairs[m * n_bj:(m + 1) * n_bj]
+                row = tmpl[m]
+                pad = n_bj - len(chunk)
+                js = torch.tensor([p[0] for p in chunk] + [chunk[0][0]] * pad)
+                bs = torch.tensor([p[1] for p in chunk] + [chunk[0][1]] * pad)
+                cl = classes[bs]                                           # [n_bj, k] class id of every unit
+                oi = (bs[:, None] * ncls + cl) * T + js[:, None]           # errors[b, class, j], flat
+                if pad:
+                    oi[len(chunk):] = dump
+                o = 2 * n_bj
+                row[0:o].view(torch.int64).copy_(bs * T + js)
+                o += 3 * n_bj
+                row[o:o + n_bj].copy_(bs.to(torch.int32)); o += n_bj
+                row[o:o + U].copy_(cl.reshape(-1).to(torch.int32)); o += U
+                row[o:o + U].copy_(oi.reshape(-1).to(torch.int32))
+                jsb.append((js, bs))
+            ent = cache[ck] = (tmpl, jsb)
+        tmpl, jsb = ent
+        host[:n_mb].copy_(tmpl)
         for m in range(n_mb):
-            chunk = pairs[m * n_bj:(m + 1) * n_bj]
-            row = host[m]
-            pad = n_bj - len(chunk)
-            js = torch.tensor([p[0] for p in chunk] + [chunk[0][0]] * pad)
-            bs = torch.tensor([p[1] for p in chunk] + [chunk[0][1]] * pad)
-            cl = classes[bs]                                           # [n_bj, k] class id of every unit
-            oi = (bs[:, None] * ncls + cl) * T + js[:, None]           # errors[b, class, j], flat
-            if pad:
-                oi[len(chunk):] = dump
+            js, bs = jsb[m]
             o = 2 * n_bj
-            row[0:o].view(torch.int64).copy_(bs * T + js)
             for src in (d["logsnr"], d["alpha"], d["sigma"]):
-                row[o:o + n_bj].view(torch.float32).copy_(src[js, bs])
+                host[m, o:o + n_bj].view(torch.float32).copy_(src[js, bs])
                 o += n_bj
-            row[o:o + n_bj].copy_(bs.to(torch.int32)); o += n_bj
-            row[o:o + U].copy_(cl.reshape(-1).to(torch.int32)); o += U
-            row[o:o + U].copy_(oi.reshape(-1).to(torch.int32))
         CHW = Cc * H * W
         for m in range(n_mb):
             chunk = pairs[m * n_bj:(m + 1) * n_bj]

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc counter CSVs (one pass per counter, as MI355X_MICROARCH.md prescribes) into
+profiles/pmc_traffic.json: per kernel FAMILY (the names bench.py / dc_igemm_variant use) the per-launch
+averages of FETCH_SIZE and WRITE_SIZE in KB.  bench.py applies the gfx950 correction (FETCH_SIZE x2) itself.
+
+  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json "comment"
+"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def family(kernel):
+    """kernel name as rocprofv3 prints it (Itanium-mangled, occasionally demangled) -> the family name bench.py
+    reports (None: not one of ours)."""
+    k = kernel.replace(" ", "")
+    dt = "bf16" if ("DF16b" in k or "__bf16" in k) else ("f16" if ("DF16_" in k or "_Float16" in k) else "f32")
+    ints = [int(v.replace("n", "-")) for v in re.findall(r"Li(n?\d+)E", k)] or [int(v) for v in re.findall(r"[<,](-?\d+)(?=[,>])", k)]
+    if "conv3_halo_kernel" in k:
+        return f"conv3_halo<{dt},{ints[0]}w>"
+    if "igemm_pipe_kernel" in k:
+        bm, st, nh = ints[0], ints[1], ints[2]
+        return f"igemm_pipe<{dt},{bm}x{128 * nh},{st}st>"
+    if "igemm_xreg_kernel" in k:
+        return "igemm_xreg<bf16,96xN>" if dt == "f32" else f"igemm_xreg<{dt},96xN>"   # demangler drops the type: 16-bit only kernel
+    if "igemm_kernel" in k:
+        return f"igemm<{dt},{ints[0]}x{ints[1]}>"
+    if "gn_" in k:
+        return "groupnorm"
+    return None
+
+
+def collect(root, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    files = glob.glob(f"{root}/**/*counter_collection.csv", recursive=True)
+    assert files, f"no counter_collection.csv under {root}"
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            fam = family(row["Kernel_Name"])
+            if fam is None:
+                continue
+            tot[fam] += float(row["Counter_Value"])
+            cnt[fam] += 1
+    return tot, cnt
+
+
+def main():
+    fetch_dir, write_dir, out, comment = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    ft, fc = collect(fetch_dir, "FETCH_SIZE")
+    wt, wc = collect(write_dir, "WRITE_SIZE")
+    rec = {"_comment": comment}
+    for fam in sorted(ft):
+        rec[fam] = {"fetch_kb_per_launch": round(ft[fam] / fc[fam], 1),
+                    "write_kb_per_launch": round(wt.get(fam, 0.0) / max(wc.get(fam, 0), 1), 1), "launches": fc[fam]}
+    json.dump(rec, open(out, "w"), indent=1)
+    for k, v in rec.items():
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
