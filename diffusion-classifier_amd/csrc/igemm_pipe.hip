@@ -31,7 +31,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // NH = 2 (BM = 256, S = 2): 256 x 256 tile, each wave 64 pixels x 128 couts — 12 fragment reads per 32 MFMAs instead of
 //                  8 per 16 and a third less LDS-DMA per MFMA (the 64x64 wave tile is LDS-bandwidth bound at ~50 % of
 //                  the matrix pipe); wide layers (Cout a multiple of 256) with long K loops
-// EV: epilogue variant compiled in: -1 = all five behind a wave-uniform switch; 0 = plain, 3 = tanh-GELU, 4 = plain + gate.
+// EV: epilogue variant compiled in: -1 = all five behind a wave-uniform switch; 0 = plain, 2 = GEGLU, 3 = tanh-GELU, 4 = plain + gate.
 //     The 256x256 kernel holds 128 accumulator registers and is instantiated per variant (several variants in one
 //     kernel pushed hipcc into spilling accumulators inside the K loop).
 // SLIM: 1-tap GEMM — the loader keeps one row pointer per source instead of the tap geometry (gating this at run time
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
   // 128-cout tile index and half inside it
   auto epi = [&](f32x4 (&ac)[TN][TM], int tile128, int half) {
     if (EV < 0) epi_direct<T, TM>(a, ac, tile128, half, lq, sf, sl, rowfn);
-    else epi_direct_act<T, TM, (EV == 3 ? DC_ACT_GELU_TANH : DC_ACT_NONE), EV == 4, false>(a, ac, tile128, half, lq, sf, sl, rowfn);
+    else epi_direct_act<T, TM, (EV == 3 ? DC_ACT_GELU_TANH : (EV == 2 ? DC_ACT_GEGLU : DC_ACT_NONE)), EV == 4, false>(a, ac, tile128, half, lq, sf, sl, rowfn);
   };
   if (NH == 1) epi(acc[0], tile_n, wn);
   else {
@@ -305,6 +305,7 @@ static int launch_pipe(const IgemmArgs& a0, hipStream_t s) {
 template <typename T>
 static int launch_wide(const IgemmArgs& a, hipStream_t s) {
   if (a.act == DC_ACT_GELU_TANH) return launch_pipe<T, 256, 2, 2, 3, true>(a, s);
+  if (a.act == DC_ACT_GEGLU) return launch_pipe<T, 256, 2, 2, 2, true>(a, s);
   if (a.gate) return launch_pipe<T, 256, 2, 2, 4, true>(a, s);
   return launch_pipe<T, 256, 2, 2, 0, true>(a, s);
 }
@@ -313,10 +314,13 @@ static int launch_wide(const IgemmArgs& a, hipStream_t s) {
 int dc_igemm_pipe_shape(const IgemmArgs& a) {
   static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
   static const bool no_wide = getenv("DCAMD_PIPE_NO_WIDE") != nullptr;
-  static const long long wide_min = getenv("DCAMD_PIPE_WIDE_MIN") ? atoll(getenv("DCAMD_PIPE_WIDE_MIN")) : 256LL * 2 * 512;   // M x (128-cout tiles)
+  static const long long wide_min_tiles = getenv("DCAMD_PIPE_WIDE_MIN_TILES") ? atoll(getenv("DCAMD_PIPE_WIDE_MIN_TILES")) : 400;
+  static const int wide_min_nk = getenv("DCAMD_PIPE_WIDE_MIN_NK") ? atoi(getenv("DCAMD_PIPE_WIDE_MIN_NK")) : 4;
+  const bool wide_act = a.act == DC_ACT_NONE || ((a.act == DC_ACT_GELU_TANH || a.act == DC_ACT_GEGLU) && !a.gate);   // the variants launch_wide has
+  // 1-tap GEMMs on wide layers: the 256x256 tile whenever it fills the chip (>= wide_min_tiles tiles), whatever K
+  if (!no_wide && wide_act && a.taps == 1 && (a.tiles_n & 1) == 0 && a.nk >= wide_min_nk &&
+      (long long)((a.M + 255) / 256) * (a.tiles_n / 2) >= wide_min_tiles) return 2;
   if (a.nk <= light_nk) return 0;
-  const bool wide_act = a.act == DC_ACT_NONE || (a.act == DC_ACT_GELU_TANH && !a.gate);     // the variants launch_wide has
-  if (!no_wide && wide_act && a.taps == 1 && (a.tiles_n & 1) == 0 && (long long)a.M * a.tiles_n >= wide_min) return 2;   // wide layer, enough 256x256 tiles to fill the chip
   return 1;
 }
 

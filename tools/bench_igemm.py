@@ -35,6 +35,15 @@ SHAPES = {
     "qkv8": (4000, 8, 8, 512, 1536, 1, False),
     "ffo8": (4000, 8, 8, 2048, 512, 1, True),
     "short32": (4000, 32, 32, 256, 128, 1, False),
+    # cfg2 transformer blocks as they really run: 8x8 (C=256) and 4x4 (C=512) tokens per unit, 4000 units
+    "t8_geglu": (4000, 8, 8, 256, 2048, 1, False, "geglu"),
+    "t8_qkv": (4000, 8, 8, 256, 768, 1, False),
+    "t8_out": (4000, 8, 8, 256, 256, 1, True),
+    "t8_ffo": (4000, 8, 8, 1024, 256, 1, True),
+    "t4_geglu": (4000, 4, 4, 512, 4096, 1, False, "geglu"),
+    "t4_qkv": (4000, 4, 4, 512, 1536, 1, False),
+    "t4_out": (4000, 4, 4, 512, 512, 1, True),
+    "t4_ffo": (4000, 4, 4, 2048, 512, 1, True),
     # DiT-B/4 GEMMs (1000 units x 1024 tokens)
     "dit_qkv": (1000, 32, 32, 768, 2304, 1, False),
     "dit_proj": (1000, 32, 32, 768, 768, 1, True),
