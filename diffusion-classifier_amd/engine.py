@@ -466,6 +466,24 @@ class UNetWeights:
         self.cv_total = o
         P["attn2v.w"] = pack_matrix(vw, L.DC_F32, device)
         self.P = P
+        self._sd = sd              # references only (no copy): split packing of skip-connection convs is lazy
+
+    def split_resnet(self, key, C0):
+        """Packed halves of a skip-connection ResNet's input convs: `.conv1.wa/.wb` ([Cout, 9*C0] / [Cout, 9*C1], same
+        k = tap*C + c order) and `.conv_shortcut.wa/.wb`, for channels [0, C0) and [C0, C0+C1) of the concatenated
+        input.  conv(cat(a, b)) = conv_a(a) + conv_b(b): when b is class-independent its half runs once per (image, trial)
+        pair instead of once per class (UNetPlan.resnet)."""
+        P, sd = self.P, self._sd
+        if key + ".conv1.wa" not in P:
+            w = sd[key + ".conv1.weight"]
+            P[key + ".conv1.wa"] = pack_conv3x3(w[:, :C0], self.dt, self.dev)
+            P[key + ".conv1.wb"] = pack_conv3x3(w[:, C0:], self.dt, self.dev)
+            if key + ".conv_shortcut.weight" in sd:
+                ws = sd[key + ".conv_shortcut.weight"]
+                ws = ws.reshape(ws.shape[0], -1)
+                P[key + ".conv_shortcut.wa"] = pack_matrix(ws[:, :C0], self.dt, self.dev)
+                P[key + ".conv_shortcut.wb"] = pack_matrix(ws[:, C0:], self.dt, self.dev)
+        return P
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.P.values())
@@ -490,6 +508,7 @@ class UNetPlan:
         # the standalone apply pass on cfg2 (the in-loop transform costs the conv more than the pass it removes),
         # so it stays opt-in until the transform overlaps the MFMA stream.
         fuse_gn = os.environ.get("DCAMD_GN_FUSION") is not None
+        split_skips = os.environ.get("DCAMD_NO_SKIP_SPLIT") is None
         cfg = model.config
         dev = device or weights.dev
         dt = weights.dt
@@ -554,12 +573,29 @@ class UNetPlan:
         def resnet(key, x0, x1=None):
             Cout = P[key + ".conv1.b"].shape[0]
             tvec = tproj.view(weights.tproj_off[key], Cout)
+            # skip connection from the class-shared trunk into a per-class layer: conv(cat(h, skip)) = conv_a(h) + conv_b(skip)
+            # and GroupNorm never mixes the two halves when its groups do not straddle the seam — the skip half is then
+            # computed once per (image, trial) pair, not once per class.  Exact algebra; only the summation order differs.
+            split = (split_skips and not fuse_gn and x1 is not None and x1.dom == "bj" and x0.dom == "unit"
+                     and x0.C % ((x0.C + x1.C) // G) == 0 and key + ".conv_shortcut.w" in P)
             # GroupNorm+SiLU is applied inside the conv's halo load where libdcamd can (the normalised tensor then never
             # exists in HBM); otherwise as its own pass
             if fuse_gn and pb.gn_fusable(x0, x1, Cout):
                 aff = pb.groupnorm_stats(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, x1=x1)
                 h = pb.igemm(key + ".conv1", x0, pb.const(P[key + ".conv1.w"]), Cout, taps=9, src1=x1,
                              bias=pb.const(P[key + ".conv1.b"]), rowvec=tvec, gn=(aff[0], aff[1], True))
+            elif split:
+                # class-independent skip half, once per (image, trial) pair: its GroupNorm groups are its own, its conv
+                # partial sum enters the per-unit conv as a residual read through bj_of_unit
+                Ca, Cb = x0.C, x1.C
+                cpg = (Ca + Cb) // G
+                weights.split_resnet(key, Ca)
+                g1, b1 = P[key + ".norm1.g"], P[key + ".norm1.b"]
+                ys = pb.groupnorm(key + ".gn1s", x1, pb.const(g1[Ca:]), pb.const(b1[Ca:]), Cb // cpg, eps, True)
+                ts = pb.igemm(key + ".conv1s", ys, pb.const(P[key + ".conv1.wb"]), Cout, taps=9)
+                yh = pb.groupnorm(key + ".gn1", x0, pb.const(g1[:Ca]), pb.const(b1[:Ca]), Ca // cpg, eps, True)
+                h = pb.igemm(key + ".conv1", yh, pb.const(P[key + ".conv1.wa"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
+                             rowvec=tvec, residual=ts)
             else:
                 h = pb.groupnorm(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, True, x1=x1)
                 h = pb.igemm(key + ".conv1", h, pb.const(P[key + ".conv1.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
@@ -569,7 +605,11 @@ class UNetPlan:
                 aff2 = pb.groupnorm_stats(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps)
             else:
                 h = pb.groupnorm(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps, True)
-            if key + ".conv_shortcut.w" in P:
+            if split and key + ".conv_shortcut.w" in P:
+                ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout)
+                sc = pb.igemm(key + ".short", x0, pb.const(P[key + ".conv_shortcut.wa"]), Cout,
+                              bias=pb.const(P[key + ".conv_shortcut.b"]), residual=ss)
+            elif key + ".conv_shortcut.w" in P:
                 sc = pb.igemm(key + ".short", x0, pb.const(P[key + ".conv_shortcut.w"]), Cout, src1=x1,
                               bias=pb.const(P[key + ".conv_shortcut.b"]))
             else:
