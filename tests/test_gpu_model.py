@@ -82,6 +82,27 @@ def test_cifar_unet_forward_f32():
     assert relerr(got, ref) < 3e-5, relerr(got, ref)
 
 
+def test_class_shared_skip_halves_match_the_unsplit_plan(monkeypatch):
+    """conv(cat(h, skip)) = conv_a(h) + conv_b(skip): the up-path ResNets whose skip comes from the class-shared trunk run
+    the skip half (GroupNorm, 3x3 conv, 1x1 shortcut) once per pair.  Same network, different summation order only."""
+    kw = dca.cifar10_unet_kwargs()
+    torch.manual_seed(8)
+    x, lam, emb = torch.randn(3, 3, 32, 32), torch.tensor([4.0, 0.5, -6.0]), torch.randn(3, 1, 128)
+    outs, names = [], []
+    for split in (True, False):
+        if split:
+            monkeypatch.delenv("DCAMD_NO_SKIP_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("DCAMD_NO_SKIP_SPLIT", "1")
+        m, _ = make_pair(kw, seed=7)
+        m = m.to(DEV)
+        outs.append(m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu())
+        plan = next(iter(m._plans.values()))
+        names.append([mt["name"] for mt in plan.pb.meta])
+    assert sum(n.endswith(".conv1s") for n in names[0]) == 5 and not any(n.endswith(".conv1s") for n in names[1])
+    assert relerr(outs[0], outs[1]) < 1e-5, relerr(outs[0], outs[1])
+
+
 def test_one_token_cross_attention_shortcut_is_exact():
     """attn2 over a single class token == to_out(to_v(ctx)) for every query (what the engine uses)."""
     kw = dca.small_unet_kwargs()
