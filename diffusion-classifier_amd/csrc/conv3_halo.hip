@@ -97,7 +97,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int ty = (tile_m / g.tiles_x) % g.tiles_y;
   const int ng = tile_m / (g.tiles_x * g.tiles_y);
   const int tw = 1 << g.ltw, th = 1 << g.lth;
-  const int HW = g.H * g.W;
+  const int HW = g.H * g.W;                             // g.H x g.W: the conv's (= output) extent; the source is half of it when upsampling
+  const int HWs = a.upsample ? (g.H >> 1) * (g.W >> 1) : HW;
   const int Ctot = a.C0 + a.C1;
   const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
 
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   if (t < (1 << g.lni)) {
     const int n = (ng << g.lni) + t;
     const bool vn = n < g.n_img;
-    tbl[2 * t] = vn ? (a.map0 ? a.map0[n] : n) * HW : -1;
-    tbl[2 * t + 1] = (vn && a.src1) ? (a.map1 ? a.map1[n] : n) * HW : -1;
+    tbl[2 * t] = vn ? (a.map0 ? a.map0[n] : n) * HWs : -1;
+    tbl[2 * t + 1] = (vn && a.src1) ? (a.map1 ? a.map1[n] : n) * HWs : -1;
   }
 #pragma unroll
   for (int i = 0; i < NXL; ++i) {
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       const int img = hr / g.hp, r = hr - img * g.hp;
       const int hy = r / g.hw, hx = r - hy * g.hw;
       const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
-      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) pp[i] = (img << 20) | (iy * g.W + ix);
+      // nearest-2x upsample folded into the gather: halo pixel (iy, ix) of the upsampled image reads source (iy>>1, ix>>1)
+      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+        pp[i] = (img << 20) | (a.upsample ? (iy >> 1) * (g.W >> 1) + (ix >> 1) : iy * g.W + ix);
     }
   }
   __syncthreads();
@@ -294,7 +297,7 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
   // plain convolutions only (bias / per-sample row vector / residual): the 128-accumulator wave tile leaves room for ONE
   // epilogue variant; an activation or a gate goes to igemm_pipe.hip (the UNets apply SiLU in the GroupNorm pass)
-  if (a.taps != 9 || a.stride != 1 || a.upsample || a.act != DC_ACT_NONE || a.gate) return false;
+  if (a.taps != 9 || a.stride != 1 || a.act != DC_ACT_NONE || a.gate) return false;
   const int H = a.Hin, W = a.Win;
   if (H < 8 || W < 8 || (H & (H - 1)) || (W & (W - 1))) return false;     // 4x4 and smaller stay on igemm_pipe
   if ((long long)a.M >= (1LL << 31)) return false;
@@ -305,7 +308,7 @@ bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
 
 // fused GroupNorm prologue: one sample per workgroup, affine table fits its LDS slot, one halo piece per remaining tap
 bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype) {
-  if (!dc_conv3_halo_applicable(a, dtype)) return false;
+  if (!dc_conv3_halo_applicable(a, dtype) || a.upsample) return false;
   static const int nw_env = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
   const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : (nw_env == 8 ? 8 : 4);
   const int pix = nw * 64, nt = nw * 64, pd = (nw == 4 ? 3 : 4) - 1;
