@@ -56,7 +56,7 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
                                                int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn()) {
   constexpr bool geglu = ACT == DC_ACT_GEGLU;
   constexpr int NK = geglu ? 1 : 2;                  // 8-channel runs per pixel
-  constexpr int JB = TM % 4 == 0 ? 4 : TM;           // pixel fragments per load batch
+  constexpr int JB = TM;                             // pixel fragments per load batch: all of them — one exposed residual latency per tile
   const int cout_out = geglu ? (a.Cout >> 1) : a.Cout;
   const int c0 = (geglu ? tile_n * 64 + wn * 32 : tile_n * 128 + wn * 64) + lq * 8;     // run k starts at c0 + 32 k
   constexpr bool res16 = sizeof(T) == 2;
