@@ -28,6 +28,7 @@ template <int N> __device__ __forceinline__ void lgkm_wait(chunk16& a) { asm vol
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ int g_xpat;   // X fragment address pattern under test (mode >= 1)
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void peak_kernel(float* out, int iters, const char* src) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -46,7 +47,17 @@ __global__ __launch_bounds__(256, 2) void peak_kernel(float* out, int iters, con
   for (int j = 0; j < 8; ++j) xf[j] = chunk16{0x3c003c00u + j, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
   const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
   const uint32_t woff = base + 49152 + (lane & 15) * 64 + (lane >> 4) * 16;
-  const uint32_t xoff = base + ((t >> 6) >> 1) * 8192 + (lane & 15) * 64 + (lane >> 4) * 16;
+  // X fragment read patterns: 0 row-major 64-B rows (conv3_halo today); 1 chunk-major planes 128 B mod 256 apart; 2 chunk-major
+  // planes 0 mod 256 apart; 3 row-major with the W tile's XOR swizzle; 4 row-major, chunk rotated by row
+  const int xp = g_xpat, lr_ = lane & 15, lq_ = lane >> 4;
+  uint32_t xlane = lr_ * 64 + lq_ * 16;
+  if (xp == 1) xlane = lq_ * (344 * 16) + lr_ * 16;
+  if (xp == 2) xlane = lq_ * (352 * 16) + lr_ * 16;
+  if (xp == 3) xlane = lr_ * 64 + ((lq_ ^ ((0x78 >> (((lr_ >> 2) & 3) << 1)) & 3)) << 4);
+  if (xp == 4) xlane = lr_ * 64 + (((lq_ + (lr_ >> 2)) & 3) << 4);
+  const uint32_t xoff = base + ((t >> 6) >> 1) * (xp == 1 || xp == 2 ? 2048 : 8192) + xlane;
+  const uint32_t xj = (xp == 1 || xp == 2) ? 256 : 1024;          // fragment j: 16 rows further
+  const uint32_t xtap = (xp == 1 || xp == 2) ? 16 : 64;           // tap: one row further
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const char* wsrc = src + t * 16;                               // 1 MiB of "weights", L2 resident
   const char* xsrc = src + (1 << 20) + (size_t)(blockIdx.x & 1023) * 24576 + t * 16;
@@ -92,12 +103,12 @@ __global__ __launch_bounds__(256, 2) void peak_kernel(float* out, int iters, con
       }
     }
     if (MODE >= 1) {
-      const uint32_t tap = (it % 9) * 64;
+      const uint32_t tap = (it % 9) * xtap;
       __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
       for (int i = 0; i < 4; ++i) wf[i] = ds_read16_async(woff + i * 1024);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = ds_read16_async(xoff + tap + j * 1024);
+      for (int j = 0; j < 8; ++j) xf[j] = ds_read16_async(xoff + tap + j * xj);
     }
 #define GROUP(J, N)                                                                     \
     if (MODE >= 1) lgkm_wait<N>(xf[J]);                                                   \
@@ -254,7 +265,13 @@ int main() {
     hipMemcpy(src, h, nb, hipMemcpyHostToDevice);
     free(h);
   }
-  for (int blocks : {512, 2048}) {
+  for (int xp = 1; xp <= 4; ++xp) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xpat), &xp, sizeof(xp));
+    char nm[64]; snprintf(nm, sizeof(nm), "X pattern %d: mfma + reads", xp);
+    run<1>(nm, out, 2048, src);
+  }
+  { int xp = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xpat), &xp, sizeof(xp)); }
+  for (int blocks : {2048}) {
     run<0>("mfma only", out, blocks, src);
     run<1>("mfma + 12 ds_read_b128 / 32 mfma", out, blocks, src);
     run<2>("  + s_barrier per step", out, blocks, src);
