@@ -10,6 +10,7 @@
 //   O = P V     (d/16 x L/32 MFMA), scaled by 1/rowsum, stored as 16-bit.
 // The fp32 kernel of attention.hip stays the path for f32 (exact) and for shapes outside
 // L % 16 == 0, d % 32 == 0.
+#include <stdlib.h>
 #include "igemm_common.h"
 
 struct AttnMArgs {
@@ -301,6 +302,196 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Flash forward, transposed-score form (head dims 32 / 64 / 128): no transposed V image, no LDS round trip for P.
+//   S^T = K Q^T     16x16x32 MFMA, A = K rows straight from a row-major LDS image, B = Q fragments held in registers;
+//                   the D fragment gives a lane 4 consecutive KEYS of ONE query (column lane&15)
+//   softmax         per query = per lane column: running max / sum live in every lane of the column, the cross-lane part
+//                   is two xor-shuffles (lanes 16 and 32 apart); exponentials as v_exp_f32 on log2-scaled scores
+//   O^T += V^T P^T  16x16x32 MFMA over PAIRS of key tiles: the two packed P^T D-fragments a lane holds ARE its B operand
+//                   (the k order inside an MFMA is free as long as A agrees), and the matching A operand (4 + 4
+//                   consecutive keys of one d column) is two ds_read_b64_tr_b16 of the ROW-MAJOR V image
+// K / V blocks of 128 / 64 / 32 keys (d = 32 / 64 / 128) are register-staged (global loads of block i+1 issued before the MFMAs of block i, written to
+// the other LDS buffer after them), one barrier per block.  The first version (attn_flash_kernel above: transposed V
+// staged with 2-byte LDS writes, P through LDS, no prefetch) ran DiT-B/4 attention at 0.2 PF.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+template <typename T> struct Mma16;
+template <> struct Mma16<__bf16> {
+  static __device__ __forceinline__ f32x4 run(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma16<_Float16> {
+  static __device__ __forceinline__ f32x4 run(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a) {
+  constexpr int KB = D <= 32 ? 128 : (D <= 64 ? 64 : 32);     // keys per block: sized so that scores + staged K/V fit the register file
+  constexpr int NKT = KB / 16, NQT = 2, NDT = D / 16, NKB = D / 32;
+  constexpr int PITCH = D + 8;                                // LDS row pitch in elements (+16 B)
+  constexpr int CPR = D / 8;                                  // 16-byte chunks per row
+  constexpr int NST = KB * CPR / 256;                         // staging chunks per thread and operand
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const Kl = reinterpret_cast<T*>(smem);                   // [2][KB][PITCH]
+  T* const Vl = Kl + 2 * KB * PITCH;                          // [2][KB][PITCH]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int L = a.L;
+  const int qblocks = (L + 127) / 128;
+  int b = blockIdx.x;
+  const int qb = b % qblocks; b /= qblocks;
+  const int h = b % a.heads, n = b / a.heads;
+  const T* qg = reinterpret_cast<const T*>(a.q) + (size_t)n * L * a.ld_qkv + h * D;
+  const T* kg = reinterpret_cast<const T*>(a.k) + (size_t)n * L * a.ld_qkv + h * D;
+  const T* vg = reinterpret_cast<const T*>(a.v) + (size_t)n * L * a.ld_qkv + h * D;
+  const int q0 = qb * 128 + wave * 32;
+
+  chunk16 qf[NQT][NKB];                                       // B operand of S^T: query lr, d = 32 kb + 8 lq .. +7
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int qi = q0 + qt * 16 + lr;
+      qf[qt][kb] = *reinterpret_cast<const chunk16*>(qg + (size_t)(qi < L ? qi : L - 1) * a.ld_qkv + kb * 32 + lq * 8);
+    }
+  f32x4 O[NQT][NDT];                                          // O^T: rows d = 16 dt + 4 lq + r, column = query lr
+  float m[NQT], l[NQT];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) {
+    m[qt] = -INFINITY; l[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) O[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sc2 = a.scale * 1.4426950408889634f;            // scores in log2 units
+
+  chunk16 ks[NST], vs[NST];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = i * 256 + t, r = idx / CPR, c = idx - r * CPR;
+      const int key = k0 + r;
+      ks[i] = chunk16{0u, 0u, 0u, 0u}; vs[i] = ks[i];
+      if (key < L) {
+        ks[i] = *reinterpret_cast<const chunk16*>(kg + (size_t)key * a.ld_qkv + c * 8);
+        vs[i] = *reinterpret_cast<const chunk16*>(vg + (size_t)key * a.ld_qkv + c * 8);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = i * 256 + t, r = idx / CPR, c = idx - r * CPR;
+      *reinterpret_cast<chunk16*>(Kl + (buf * KB + r) * PITCH + c * 8) = ks[i];
+      *reinterpret_cast<chunk16*>(Vl + (buf * KB + r) * PITCH + c * 8) = vs[i];
+    }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int nblk = (L + KB - 1) / KB;
+  for (int ib = 0; ib < nblk; ++ib) {
+    const int k0 = ib * KB, buf = ib & 1;
+    if (ib + 1 < nblk) fetch(k0 + KB);                        // lands under this block's MFMAs
+    const T* Kb = Kl + buf * KB * PITCH;
+    const T* Vb = Vl + buf * KB * PITCH;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+      f32x4 S[NKT];
+      float mx = m[qt];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          const chunk16 kf = *reinterpret_cast<const chunk16*>(Kb + (kt * 16 + lr) * PITCH + kb * 32 + lq * 8);
+          acc = Mma<T>::run(kf, qf[qt][kb], acc);             // rows = keys, column = query
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool kvalid = k0 + kt * 16 + lq * 4 + r < L;  // keys past L never win the max nor add to the sum
+          acc[r] = kvalid ? acc[r] * sc2 : -INFINITY;
+          mx = fmaxf(mx, acc[r]);
+        }
+        S[kt] = acc;
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float corr = __builtin_amdgcn_exp2f(m[qt] - mx);  // exp2(-inf) = 0 on the first block
+      m[qt] = mx;
+      float ps = 0.f;
+      s16x4 P[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        float pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(S[kt][r] - mx); ps += pv[r]; }
+        typename Elem<T>::vec4 pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk[r] = Elem<T>::from_f(pv[r]);
+        P[kt] = __builtin_bit_cast(s16x4, pk);
+      }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      l[qt] = l[qt] * corr + ps;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        f32x4 acc = O[qt][dt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= corr;
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+          // one 16x16x32 MFMA per PAIR of key tiles: the sum over k is order-free as long as both operands agree, so lane
+          // group lq takes as its 8 k-slots the keys 4 lq .. +3 of tile 2 kp and of tile 2 kp + 1 — exactly the two packed P^T
+          // D-fragments it already holds (B operand), and two transposed reads of the row-major V image (A operand): for each,
+          // the 16-lane group takes keys 16 kt + 4 lq .. +3 x d columns 16 dt .. +15; lane 4q+p supplies the address of key
+          // row q, columns 4p .. 4p+3 and receives column lr of the four rows
+          s16x4 vf[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const T* vp = Vb + ((2 * kp + u) * 16 + lq * 4 + (lr >> 2)) * PITCH + dt * 16 + (lr & 3) * 4;
+            vf[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(const_cast<T*>(vp)));
+          }
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 av = __builtin_shufflevector(vf[0], vf[1], 0, 1, 2, 3, 4, 5, 6, 7);
+          const s16x8 bv = __builtin_shufflevector(P[2 * kp], P[2 * kp + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc = Mma<T>::run(__builtin_bit_cast(chunk16, av), __builtin_bit_cast(chunk16, bv), acc);   // rows = d, column = query
+        }
+        O[qt][dt] = acc;
+      }
+    }
+    if (ib + 1 < nblk) stash(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) {
+    const int qi = q0 + qt * 16 + lr;
+    if (qi >= L) continue;
+    const float inv = 1.0f / l[qt];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      typename Elem<T>::vec4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = Elem<T>::from_f(O[qt][dt][r] * inv);
+      *reinterpret_cast<typename Elem<T>::vec4*>(reinterpret_cast<T*>(a.out) + ((size_t)n * L + qi) * a.ld_out + h * D + dt * 16 + lq * 4) = o;
+    }
+  }
+}
+
+template <typename T, int D>
+static int launch_flash_t(const FlashArgs& a, long long nb, hipStream_t s) {
+  constexpr int KB = D <= 32 ? 128 : (D <= 64 ? 64 : 32);
+  constexpr size_t lds = (size_t)4 * KB * (D + 8) * 2;
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_flash_t_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  hipLaunchKernelGGL((attn_flash_t_kernel<T, D>), dim3((unsigned)nb), dim3(256), lds, s, a);
+  return dc_check_launch("dc_attention(flash_t)");
+}
+
 bool dc_attn_flash_applicable(int dtype, int L, int d) { return dtype != DC_F32 && d % 32 == 0 && d <= 128 && L >= 1; }
 
 int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s) {
@@ -312,6 +503,13 @@ int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s) {
   const size_t lds = ((size_t)128 * (p->d + 8) + (size_t)p->d * 136 + (size_t)4 * 32 * 136) * 2;
   const long long nb = (long long)p->n * p->heads * ((p->L + 127) / 128);
   if (nb >= (1LL << 31)) { dc_set_error("dc_attention: grid too large"); return DC_ERR_SHAPE; }
+  static const bool old_flash = getenv("DCAMD_ATTN_FLASH_V1") != nullptr;
+  if (!old_flash && (p->d == 32 || p->d == 64 || p->d == 128) && p->ld_out % 4 == 0 && (((uintptr_t)p->out) & 7) == 0) {
+    const bool bf = p->dtype == DC_BF16;
+    if (p->d == 32) return bf ? launch_flash_t<__bf16, 32>(a, nb, s) : launch_flash_t<_Float16, 32>(a, nb, s);
+    if (p->d == 64) return bf ? launch_flash_t<__bf16, 64>(a, nb, s) : launch_flash_t<_Float16, 64>(a, nb, s);
+    return bf ? launch_flash_t<__bf16, 128>(a, nb, s) : launch_flash_t<_Float16, 128>(a, nb, s);
+  }
   static bool done_b = false, done_h = false;
   if (p->dtype == DC_BF16) {
     if (!done_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_flash_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_b = true; }

@@ -30,12 +30,14 @@ template <> struct Elem<float> {
 };
 template <> struct Elem<__bf16> {
   using vec = bf16x8;
+  typedef __attribute__((ext_vector_type(4))) __bf16 vec4;      // 8 bytes: one 16x16x16 MFMA operand / one 4-element store
   static constexpr int EPC = 8;
   static __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
   static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }  // RNE, NaN-preserving
 };
 template <> struct Elem<_Float16> {
   using vec = f16x8;
+  typedef __attribute__((ext_vector_type(4))) _Float16 vec4;
   static constexpr int EPC = 8;
   static __device__ __forceinline__ float to_f(_Float16 v) { return (float)v; }
   static __device__ __forceinline__ _Float16 from_f(float v) { return (_Float16)v; }
