@@ -59,8 +59,8 @@ template <int NW> struct HaloCfg {
   static constexpr int WR = NW == 4 ? 3 : 4;            // W ring stages (prefetch distance WR-1 taps); 3 keeps NW=4 at 72 KiB -> 2 per CU
   static constexpr int GNOFF = 2 * XBUF + WR * HALO_WST; // fused-GroupNorm affine of the workgroup's sample: scale[C], shift[C]
   static constexpr int GNMAXC = 512;
-  static constexpr int TBLOFF = GNOFF + 2 * GNMAXC * 4;  // per-image sample bases of the two sources: int [ni <= 8][2]
-  static constexpr int LDS_MAIN = TBLOFF + 64;
+  static constexpr int TBLOFF = GNOFF + 2 * GNMAXC * 4;  // per-image sample bases of the sources: int [ni <= 8][4] (src0, src1, src2, -)
+  static constexpr int LDS_MAIN = TBLOFF + 128;
   static constexpr int LDS = LDS_MAIN;
 };
 
@@ -112,8 +112,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   if (t < (1 << g.lni)) {
     const int n = (ng << g.lni) + t;
     const bool vn = n < g.n_img;
-    tbl[2 * t] = vn ? (a.map0 ? a.map0[n] : n) * HWs : -1;
-    tbl[2 * t + 1] = (vn && a.src1) ? (a.map1 ? a.map1[n] : n) * HWs : -1;
+    tbl[4 * t] = vn ? (a.map0 ? a.map0[n] : n) * HWs : -1;
+    tbl[4 * t + 1] = (vn && a.src1) ? (a.map1 ? a.map1[n] : n) * HWs : -1;
+    tbl[4 * t + 2] = (vn && a.src2) ? (a.map2 ? a.map2[n] : n) * HWs : -1;
   }
 #pragma unroll
   for (int i = 0; i < NXL; ++i) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     }
   }
   __syncthreads();
-  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (t & 3) * 16;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);      // wave-uniform (any 16 zero bytes do)
 
   // ---- fused GroupNorm(+SiLU) prologue: y = act(x*scale[n][c] + shift[n][c]) applied IN PLACE on the landed halo ----
   // (one sample per workgroup; every lane transforms exactly the 16-byte chunks it fetched, and skips padding rows,
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     __syncthreads();
   }
   auto xform = [&](int ccx, int i) {
-    if (i < g.nxl && pp[i] >= 0 && tbl[2 * (pp[i] >> 20)] >= 0) {
+    if (i < g.nxl && pp[i] >= 0 && tbl[4 * (pp[i] >> 20)] >= 0) {
       chunk16* p = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (i * NT + t) * 16);
       float f[EPC];
       chunk_to_f<T>(*p, f);
@@ -165,36 +166,54 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     }
   };
 
-  auto issue_x = [&](int cc) {
-    const bool s1 = cc >= c0chunks;
-    const T* src = reinterpret_cast<const T*>(s1 ? a.src1 : a.src0);
-    const int ld = s1 ? a.ld1 : a.ld0;
-    const int coff = (s1 ? cc - c0chunks : cc) * BKE + xlx * EPC;
+  auto issue_x = [&](int cc) {                       // cc >= nchunks: chunk cc - nchunks of the 1x1 side source
+    const int which = cc >= nchunks ? 2 : (cc >= c0chunks ? 1 : 0);
+    const T* src = reinterpret_cast<const T*>(which == 2 ? a.src2 : (which == 1 ? a.src1 : a.src0));
+    const int ld = which == 2 ? a.ld2 : (which == 1 ? a.ld1 : a.ld0);
+    const int coff = (which == 2 ? cc - nchunks : (which == 1 ? cc - c0chunks : cc)) * BKE + xlx * EPC;
     char* xs = smem + (cc & 1) * Cfg::XBUF + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       // always NXL instructions (pieces past the halo fetch the zero page into the unused tail of the buffer):
       // the counted vmcnt waits of the tap loop are then compile-time constants
-      const int base = pp[i] < 0 ? -1 : tbl[2 * (pp[i] >> 20) + (s1 ? 1 : 0)];
-      const size_t e = (size_t)(base < 0 ? 0 : base + (pp[i] & 0xFFFFF)) * ld + coff;
+      int pk = pp[i];
+      asm volatile("" : "+v"(pk));        // decode HERE, once per chunk: hoisted out of the tap loop the fields cost 2 VGPRs per piece
+      const int base = pk < 0 ? -1 : tbl[4 * (pk >> 20) + which];
+      const size_t e = (size_t)(base < 0 ? 0 : base + (pk & 0xFFFFF)) * ld + coff;
       const char* gp = base < 0 ? zero : reinterpret_cast<const char*>(src + e);
       __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
     }
   };
   // ---- W loader: 128 couts x 64 B per (chunk, tap): position i*NT + t -> row >>2, phys chunk &3 (swizzled) ----
-  const T* wrow[WLD];
-#pragma unroll
-  for (int i = 0; i < WLD; ++i) {
-    const int row = (i * NT + t) >> 2;
-    wrow[i] = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128 + epi_wrow(row, false)) * a.Ktot + ((t & 3) ^ swz64(row)) * EPC;
-  }
+  // element offset of the lane's W row chunk from the tile's first row (32-bit: Cout_pad*Ktot < 2^31), recomputed at every
+  // issue from an opaque copy of t (a handful of VALU per tap) instead of living in VGPRs through the tap loop
   auto issue_w = [&](int cc, int tap, int slot) {
-    const size_t koff = (size_t)tap * Ctot + (size_t)cc * BKE;
+    const T* wb = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128) * a.Ktot + (size_t)tap * Ctot + (size_t)cc * BKE;   // wave-uniform
+    int tt = t;
+    asm volatile("" : "+v"(tt));
 #pragma unroll
-    for (int i = 0; i < WLD; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wrow[i] + koff),
+    for (int i = 0; i < WLD; ++i) {
+      const int row = (i * NT + tt) >> 2;
+      const int wro = epi_wrow(row, false) * a.Ktot + ((tt & 3) ^ swz64(row)) * EPC;
+      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wb + wro),
                                        (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
+    }
   };
+
+  // side source weights W2 [Cout_pad][C2]: chunk e of 32 channels, same LDS tile image; the row pointers are rebuilt here
+  // (a handful of VALU, nx times per tile) rather than kept in registers through the tap loop
+  auto issue_w2 = [&](int e, int slot) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));          // keep the address arithmetic HERE (hoisted, it would sit in VGPRs through the whole tap loop)
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int row = (i * NT + tt) >> 2;
+      const T* wp = reinterpret_cast<const T*>(a.W2) + (size_t)(tile_n * 128 + epi_wrow(row, false)) * a.C2 + ((tt & 3) ^ swz64(row)) * EPC + e * BKE;
+      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wp),
+                                       (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
+    }
+  };
+  const int nx = a.src2 ? a.C2 / BKE : 0;            // 32-channel chunks of the side source (>= 2 when present)
 
   // ---- fragment read addresses: per-lane part (one register each) + wave-uniform part per fragment (SGPRs) ----
   // pixel p = wm*128 + j*16 + lr: the lr bits never carry into the bit fields set by j (tile widths are >= 8 and a
@@ -215,6 +234,26 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // one tap of one channel chunk: W fragments, then the X fragments in two halves that share registers (all eight at once
+  // need 16 more VGPRs than this kernel has: a spill inside the tap loop is reloaded behind vmcnt(0), which drains the
+  // LDS-DMA ring); MFMAs in j-major order.  The sched_barrier keeps hipcc from hoisting the second half's reads.
+  auto mma_tap = [&](const char* Wst, const char* Xb, int tapoff) {
+    chunk16 wf[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff0 + i * 1024);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      chunk16 xf[TM / 2];
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[h * (TM / 2) + j]) + xl);
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i][h * (TM / 2) + j] = Mma<T>::run(wf[i], xf[j], acc[i][h * (TM / 2) + j]);
+      if (h == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   DC_STAMP(1);
   // ---- tap loop: the 9 taps of a channel chunk are unrolled, so tap offsets, ring slots and every counted vmcnt
   // are compile-time constants (the rolled loop spent ~300 cycles of scalar control per 512-cycle MFMA block).
@@ -229,7 +268,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   }
   constexpr int FLY = (PD - 1) * WLD;                // W(s+1) .. W(s+PD-1)
   for (int cc = 0; cc < nchunks; ++cc) {
-    const bool has_next = cc + 1 < nchunks;
+    // "has_next": another X chunk and more W groups follow this chunk — the next 3x3 chunk, or the first chunk of the
+    // 1x1 side source, whose W2 tiles simply continue the W stream (s >= NS)
+    const bool side_next = cc + 1 == nchunks && nx > 0;
+    const bool has_next = cc + 1 < nchunks || side_next;
     const int s0 = cc * 9;
     const char* Xb = smem + (cc & 1) * Cfg::XBUF;
     auto step = [&](auto tapc) {
@@ -247,30 +289,39 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       __builtin_amdgcn_s_barrier();
       constexpr int t2 = tap + PD;                    // the W group to issue now: s + PD
       if (t2 < 9) issue_w(cc, t2, (s0 + t2) % WR);
+      else if (side_next) { if (t2 - 9 < nx) issue_w2(t2 - 9, (s0 + t2) % WR); }
       else if (has_next) issue_w(cc + 1, t2 - 9, (s0 + t2) % WR);
       if (tap == 0 && has_next) issue_x(cc + 1);
 
       const char* Wst = Wring + ((s0 + tap) % WR) * HALO_WST;
       constexpr int ky = tap / 3, kx = tap - ky * 3;
       const int tapoff = (ky * g.hw + kx) * 64;
-      chunk16 xf[TM], wf[TN];
-      // W fragments first, then X; MFMAs in j-major order.  (Issuing all 12 reads asynchronously with counted lgkmcnt
-      // waits — as igemm_pipe.hip does — measured no faster here: the second workgroup on the CU already fills the
-      // matrix pipe while this wave waits for a fragment.)
-#pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff0 + i * 1024);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[j]) + xl);
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+      mma_tap(Wst, Xb, tapoff);
       // X(cc+1) was issued at tap 0 and this lane's own pieces were waited for at tap PD+1: from then on transform
       // one piece per tap, behind this tap's MFMAs (other waves read the buffer only after the next chunk's barrier)
       if (gn && tap > PD && has_next) xform(cc + 1, tap > PD ? tap - PD - 1 : 0);
     };
     step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{});
     step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
+  }
+
+  // ---- 1x1 side source (a ResNet's conv_shortcut folded into its conv2): nx steps of ONE tap (the centre) each.  X2(0)
+  // and W2(0 .. PD-1) were issued inside the last 3x3 chunk; a step needs a fresh halo chunk per 32 MFMAs, so from the second
+  // step on the loads of the previous step are simply drained (vmcnt 0): ~2 k exposed cycles per step, against the whole
+  // shortcut GEMM launch and the residual round trip this replaces. ----
+  if (!gn) {
+    const int NSm = nchunks * 9;
+    for (int e = 0; e < nx; ++e) {
+      if (e == 0 && nx >= PD) hwait_vmcnt<FLY>();      // W2(1 .. PD-1) may stay in flight; X2(0) landed long ago
+      else hwait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (e + PD < nx) issue_w2(e + PD, (NSm + e + PD) % WR);
+      if (e + 1 < nx) issue_x(nchunks + e + 1);
+      const char* Xb = smem + ((nchunks + e) & 1) * Cfg::XBUF;
+      const char* Wst = Wring + ((NSm + e) % WR) * HALO_WST;
+      const int tapoff = (g.hw + 1) * 64;              // centre tap
+      mma_tap(Wst, Xb, tapoff);
+    }
   }
 
   DC_STAMP(2);

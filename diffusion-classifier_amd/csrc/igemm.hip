@@ -173,6 +173,15 @@ extern "C" int32_t dc_igemm_gn_fusable(const dc_igemm_params* p) {
   return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
 }
 
+extern "C" int32_t dc_igemm_side_ok(const dc_igemm_params* p) {
+  if (!p) return 0;
+  dc_igemm_params q = *p;
+  alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!q.src2) { q.src2 = dummy; q.W2 = dummy; }
+  const char* v = nullptr;
+  return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
+}
+
 extern "C" const char* dc_igemm_variant(const dc_igemm_params* p) {
   const char* v = "invalid";
   (void)igemm_run(p, nullptr, &v);
@@ -221,6 +230,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   a.rowvec = p->rowvec; a.rowvec_map = p->rowvec_map; a.gate = p->gate; a.gate_map = p->gate_map;
   a.residual = p->residual; a.res_map = p->res_map; a.out = p->out;
   a.gn_scale = p->gn_scale; a.gn_shift = p->gn_shift; a.gn_silu = p->gn_silu;
+  a.src2 = p->src2; a.map2 = p->map2; a.W2 = p->W2; a.C2 = p->C2; a.ld2 = p->ld2 ? p->ld2 : p->C2;
   DC_REQUIRE((p->gn_scale == nullptr) == (p->gn_shift == nullptr), DC_ERR_ARG, "dc_igemm: gn_scale/gn_shift must both be set or null");
   a.C0 = p->C0; a.C1 = p->C1; a.ld0 = p->ld0 ? p->ld0 : p->C0; a.ld1 = p->ld1 ? p->ld1 : p->C1;
   a.rowvec_ld = p->rowvec_ld; a.gate_ld = p->gate_ld; a.res_dtype = p->res_dtype;
@@ -252,6 +262,16 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   static const int halo_nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
   const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
+  if (a.src2) {
+    const int bke64 = 64 / dc_dtype_size(p->dtype);
+    const bool side_ok = halo_ok && !a.gn_scale && !a.upsample && a.W2 && a.C2 >= 2 * bke64 && a.C2 % bke64 == 0 && a.ld2 % epc == 0 &&
+                         (((uintptr_t)a.src2 | (uintptr_t)a.W2) & 15) == 0 && lane_epi_ok;
+    if (!side_ok) {
+      if (variant) { *variant = "side-source-unsupported"; return DC_ERR_UNSUPPORTED; }
+      dc_set_error("dc_igemm: src2/W2 given but this problem cannot take the 1x1 side source (see dc_igemm_side_ok)");
+      return DC_ERR_UNSUPPORTED;
+    }
+  }
   if (a.gn_scale && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
     if (variant) { *variant = "gn-not-fusable"; return DC_ERR_UNSUPPORTED; }
     dc_set_error("dc_igemm: gn_scale/gn_shift given but this problem cannot take the fused GroupNorm prologue (see dc_igemm_gn_fusable)");

@@ -113,7 +113,8 @@ class PlanBuilder:
 
     # ---- ops -----------------------------------------------------------------------
     def igemm(self, name, src0, W, Cout, *, taps=1, stride=1, upsample=0, src1=None, bias=None, rowvec=None,
-              act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None, gn=None):
+              act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None, gn=None,
+              side=None):
         dom = dom or self._dom(src0, src1, rowvec, gate, residual)
         Hin, Win = (src0.H * 2, src0.W * 2) if upsample else (src0.H, src0.W)
         if taps == 9:
@@ -134,6 +135,10 @@ class PlanBuilder:
                  res_dtype=residual.dt if residual is not None else 0,
                  res_ld=residual.ld if residual is not None else 0,
                  out=out, out_dtype=out.dt, out_ld=out.ld)
+        if side is not None:     # (src2, W2): 1x1 side source summed into the same output (conv_shortcut folded into conv2)
+            s2, W2 = side
+            assert (s2.H, s2.W) == (Hout, Wout) and s2.dt == src0.dt
+            f.update(src2=s2, map2=self._map(s2, dom), W2=W2, C2=s2.C, ld2=s2.ld)
         if gn is not None:       # fused GroupNorm(+SiLU) prologue: (scale, shift, silu) from groupnorm_stats
             assert gn[0].dom == dom and gn[0].C == f["C0"] + f["C1"], "GroupNorm affine must live in the conv's domain"
             f.update(gn_scale=gn[0], gn_shift=gn[1], gn_silu=int(gn[2]))
@@ -147,8 +152,21 @@ class PlanBuilder:
         meta = dict(name=name, family=f"igemm_{'f32' if f['dtype'] == L.DC_F32 else 'bf16' if f['dtype'] == L.DC_BF16 else 'f16'}_n{tile_n}",
                     flops=2.0 * M * kreal * Cout, bytes=float(in_bytes + kreal * Cout * es + M * cout_out * DT_SIZE[out.dt]),
                     M=M, N=Cout, K=kreal, taps=taps)
-        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []), [out], meta)
+        if side is not None:
+            meta["flops"] += 2.0 * M * side[0].C * Cout
+            meta["K"] = kreal + side[0].C
+        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []) + ([side[0]] if side else []), [out], meta)
         return out
+
+    def side_ok(self, src0, s2, Cout, residual=None):
+        """Can a 3x3 stride-1 conv of src0 take the 1x1 side source s2 (dc_igemm_side_ok)?"""
+        fake = 1 << 20
+        dom = self._dom(src0, s2, residual)
+        p = L.IgemmParams(dtype=src0.dt, taps=9, stride=1, upsample=0, n_img=self.n[dom], Hin=src0.H, Win=src0.W,
+                          Hout=src0.H, Wout=src0.W, src0=fake, C0=src0.C, ld0=src0.ld, W=fake, Cout=Cout, tile_n=128,
+                          residual=fake if residual is not None else None, res_dtype=src0.dt, res_ld=Cout,
+                          out=fake, out_dtype=src0.dt, out_ld=Cout, src2=fake, W2=fake, C2=s2.C, ld2=s2.ld)
+        return bool(L.lib().dc_igemm_side_ok(p))
 
     def gn_fusable(self, src0, src1, Cout):
         """Can a 3x3 stride-1 conv of these sources take the GroupNorm prologue (dc_igemm_gn_fusable)?"""
@@ -509,6 +527,7 @@ class UNetPlan:
         # so it stays opt-in until the transform overlaps the MFMA stream.
         fuse_gn = os.environ.get("DCAMD_GN_FUSION") is not None
         split_skips = os.environ.get("DCAMD_NO_SKIP_SPLIT") is None
+        fold_short = os.environ.get("DCAMD_NO_SHORT_FOLD") is None
         cfg = model.config
         dev = device or weights.dev
         dt = weights.dt
@@ -605,6 +624,17 @@ class UNetPlan:
                 aff2 = pb.groupnorm_stats(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps)
             else:
                 h = pb.groupnorm(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps, True)
+            # conv_shortcut folded into conv2: the 1x1 over the raw input becomes extra K chunks of conv2's own MFMA loop
+            # (conv3_halo side source) — no shortcut launch, no shortcut tensor written and read back
+            fold = (fold_short and not fuse2 and key + ".conv_shortcut.w" in P and (x1 is None or split)
+                    and pb.side_ok(h, x0, Cout, residual=x1 if split else None))
+            if fold:
+                if key + ".conv2.bs" not in P:
+                    P[key + ".conv2.bs"] = (P[key + ".conv2.b"] + P[key + ".conv_shortcut.b"]).contiguous()
+                ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout) if split else None
+                w2 = P[key + ".conv_shortcut.wa"] if split else P[key + ".conv_shortcut.w"]
+                return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.bs"]),
+                                residual=ss, side=(x0, pb.const(w2)))
             if split and key + ".conv_shortcut.w" in P:
                 ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout)
                 sc = pb.igemm(key + ".short", x0, pb.const(P[key + ".conv_shortcut.wa"]), Cout,

@@ -101,6 +101,10 @@ typedef struct {
    * real pixels (conv padding stays 0).  Only where dc_igemm_gn_fusable() says so (3x3 halo kernel, one sample
    * per workgroup, C0+C1 <= 512); NULL otherwise. */
   const float* gn_scale; const float* gn_shift; int32_t gn_silu, pad3_;
+  /* optional 1x1 side source summed into the same output (a ResNet's conv_shortcut folded into its conv2):
+   * out += sum_c A2[row, c] * W2p[co, c], A2 = src2 [*, Hout, Wout, C2] read through map2, W2p packed [Cout_pad][C2].
+   * Only where dc_igemm_side_ok() says so (3x3 stride-1 halo kernel, no upsample); NULL / 0 otherwise. */
+  const void* src2; const int32_t* map2; const void* W2; int32_t C2, ld2;
 } dc_igemm_params;
 int dc_igemm(const dc_igemm_params* p, dc_stream s);
 int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
@@ -109,6 +113,8 @@ int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
 const char* dc_igemm_variant(const dc_igemm_params* p);
 /* 1 when dc_igemm can take gn_scale/gn_shift for this problem (the other fields as for dc_igemm). */
 int32_t dc_igemm_gn_fusable(const dc_igemm_params* p);
+/* 1 when dc_igemm can take the 1x1 side source src2 / W2 for this problem. */
+int32_t dc_igemm_side_ok(const dc_igemm_params* p);
 
 /* ---------------------------------------------------------------- norms ---------- */
 /* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.

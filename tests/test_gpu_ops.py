@@ -44,7 +44,7 @@ def run_igemm(**kw):
 
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
-@pytest.mark.parametrize("case", ["plain", "stride2", "upsample", "concat", "maps", "small_n", "ragged_m"])
+@pytest.mark.parametrize("case", ["plain", "stride2", "upsample", "concat", "maps", "small_n", "ragged_m", "side", "side_maps"])
 def test_conv3x3(dt, case):
     torch.manual_seed(1)
     g = E.bke(dt)
@@ -75,6 +75,18 @@ def test_conv3x3(dt, case):
     if up:
         xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
     ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    side = None
+    if case.startswith("side"):          # 1x1 side source summed into the same output (conv_shortcut folded into conv2)
+        C2 = 2 * g
+        if case == "side_maps":
+            n_out = 5
+            m = torch.tensor([1, 1, 0, 2, 0], dtype=torch.int32)
+            ref = ref[m.long()]
+            map0 = m.to(DEV)
+        x2 = q(torch.randn(n_out, C2, H, W))
+        w2 = q(torch.randn(Cout, C2) / C2 ** 0.5)
+        ref = ref + torch.einsum("nchw,oc->nohw", x2, w2)
+        side = (nhwc(x2, dt), E.pack_matrix(w2, dt, DEV), C2)
     Hin, Win = xin.shape[2:]
     Ho, Wo = ref.shape[2:]
     rv = torch.randn(n_out, Cout)
@@ -88,7 +100,8 @@ def test_conv3x3(dt, case):
               src0=ptr(a0), map0=ptr(map0), C0=C0, ld0=0, src1=ptr(a1), map1=ptr(map0) if C1 else None, C1=C1, ld1=0,
               W=ptr(Wp), Cout=Cout, tile_n=tile_n, bias=ptr(bd), rowvec=ptr(rvd), rowvec_map=None, rowvec_ld=Cout,
               act=L.ACT_NONE, residual=ptr(resd), res_map=None, res_dtype=dt, res_ld=Cout,
-              out=ptr(out), out_dtype=dt, out_ld=Cout)
+              out=ptr(out), out_dtype=dt, out_ld=Cout,
+              src2=ptr(side[0]) if side else None, W2=ptr(side[1]) if side else None, C2=side[2] if side else 0, ld2=0)
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     assert maxrel(got, ref) < TOL[dt], (case, maxrel(got, ref))
