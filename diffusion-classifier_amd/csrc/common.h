@@ -58,6 +58,11 @@ __device__ __forceinline__ chunk16 f_to_chunk(const float* f) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// 16-bit outputs: v_exp_f32 + v_rcp_f32 (~1 ulp each, the result is rounded to 8 / 11 mantissa bits anyway) instead of ocml expf
+// and the IEEE divide (~20 VALU ops): the GroupNorm(+SiLU) pass is otherwise co-limited by VALU issue (~200 instructions per
+// 16-byte chunk against ~6 TB/s of VALU-side ceiling), and the GEGLU epilogue was VALU-bound outright
+__device__ __forceinline__ float silu_fast_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+template <typename T> __device__ __forceinline__ float silu_t(float x) { return sizeof(T) == 2 ? silu_fast_f(x) : silu_f(x); }
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute): 1 rcp + 1 exp + 5 fma instead of ocml erff's
 // ~40 VALU ops — the GEGLU epilogue evaluates it for every output element (it was ~1/3 of that GEMM's time).
 __device__ __forceinline__ float erf_as_f(float z) {
@@ -68,12 +73,26 @@ __device__ __forceinline__ float erf_as_f(float z) {
   return copysignf(r, z);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_fast_f(float x) {       // same formula on v_rcp_f32 / v_exp_f32 (16-bit outputs)
+  const float z = x * 0.70710678118654752440f, az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);
+  return 0.5f * x * (1.0f + copysignf(r, z));
+}
+template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) { return sizeof(T) == 2 ? gelu_erf_fast_f(x) : gelu_erf_f(x); }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float k = 0.79788456080286535588f;  // sqrt(2/pi)
   // 0.5 x (1 + tanh u) == x / (1 + exp(-2u)): one exp + one divide instead of ocml tanhf (the DiT fc1 epilogue was
   // VALU-bound on it); exp(-2u) -> inf / 0 at the tails gives the exact limits -0 / x
   const float u = k * (x + 0.044715f * x * x * x);
   return x / (1.0f + expf(-2.0f * u));
+}
+
+template <typename T> __device__ __forceinline__ float gelu_tanh_t(float x) {
+  if (sizeof(T) != 2) return gelu_tanh_f(x);
+  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));     // exp(-2u) on v_exp_f32
 }
 
 // store one value of runtime dtype

@@ -177,11 +177,11 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           if (geglu) {       // value fragments 0 / 2 receive the product; the gate fragments are dead afterwards
-            acc[(e >> 2) * 2][j][e & 3] = acc[(e >> 2) * 2][j][e & 3] * gelu_erf_f(acc[(e >> 2) * 2 + 1][j][e & 3]) + rf[e];
+            acc[(e >> 2) * 2][j][e & 3] = acc[(e >> 2) * 2][j][e & 3] * gelu_erf_t<T>(acc[(e >> 2) * 2 + 1][j][e & 3]) + rf[e];
           } else {
             float x = acc[2 * k + (e >> 2)][j][e & 3];
-            if (ACT == DC_ACT_SILU) x = silu_f(x);
-            if (ACT == DC_ACT_GELU_TANH) x = gelu_tanh_f(x);
+            if (ACT == DC_ACT_SILU) x = silu_t<T>(x);
+            if (ACT == DC_ACT_GELU_TANH) x = gelu_tanh_t<T>(x);
             if (GATE) x *= gt[e];
             acc[2 * k + (e >> 2)][j][e & 3] = x + rf[e];
           }

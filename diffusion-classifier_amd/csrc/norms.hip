@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         float v = f[e] * sc[e] + sh[e];
-        if (a.silu) v = silu_f(v);
+        if (a.silu) v = silu_t<T>(v);
         f[e] = v;
       }
       TO* o = reinterpret_cast<TO*>(a.y) + ((size_t)n * a.HW + p) * C + (size_t)col * EPC;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float v = f[e] * sc[e] + sh[e];
-      if (a.silu) v = silu_f(v);
+      if (a.silu) v = silu_t<T>(v);
       f[e] = v;
     }
     return f_to_chunk<T>(f);
