@@ -342,6 +342,150 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   DC_STAMP(7);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Thin-output variant (Cout <= 16: the UNets' conv_out, 3-12 channels): same 256-pixel halo patch and X loader, but ONE
+// 16-cout MFMA fragment; the four waves split the patch (64 pixels each).  The layer reads ~1 GB of activations for 3
+// output channels: it is bound by that read, and the tap-gather kernel it replaces (igemm_kernel<128x32>) re-read every
+// pixel nine times from L2 (0.93 ms against ~0.3 ms of HBM time).  All nine W[tap] tiles of a chunk (16 couts x 64 B each)
+// are fetched with the chunk's halo; one barrier per CHUNK.  Epilogue: bias only, element stores (fp32 or 16-bit output).
+struct ThinCfg {
+  static constexpr int NT = 256, NXL = 6;
+  static constexpr int XBUF = NXL * NT * 16;                 // 24 KiB per halo buffer
+  static constexpr int WBUF = 3 * NT * 16;                   // nine 1-KiB tap tiles inside the 12 KiB that 3 x 256 lanes x 16 B write
+  static constexpr int TBLOFF = 2 * XBUF + 2 * WBUF;
+  static constexpr int LDS = TBLOFF + 128;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3_thin_kernel(const IgemmArgs a, const HaloGeom g) {
+  using Cfg = ThinCfg;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BKE = 4 * EPC;
+  constexpr int TM = 4, NT = Cfg::NT, NXL = Cfg::NXL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Wl = smem + 2 * Cfg::XBUF;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int tile_m = blockIdx.x;
+  const int tx = tile_m % g.tiles_x;
+  const int ty = (tile_m / g.tiles_x) % g.tiles_y;
+  const int ng = tile_m / (g.tiles_x * g.tiles_y);
+  const int tw = 1 << g.ltw, th = 1 << g.lth;
+  const int HW = g.H * g.W;
+  const int Ctot = a.C0 + a.C1;
+  const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
+
+  int pp[NXL];
+  const int xlx = t & 3;
+  int* const tbl = reinterpret_cast<int*>(smem + Cfg::TBLOFF);
+  if (t < (1 << g.lni)) {
+    const int n = (ng << g.lni) + t;
+    const bool vn = n < g.n_img;
+    tbl[4 * t] = vn ? (a.map0 ? a.map0[n] : n) * HW : -1;
+    tbl[4 * t + 1] = (vn && a.src1) ? (a.map1 ? a.map1[n] : n) * HW : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NXL; ++i) {
+    const int hr = (i * NT + t) >> 2;
+    pp[i] = -1;
+    if (i < g.nxl && hr < g.HR) {
+      const int img = hr / g.hp, r = hr - img * g.hp;
+      const int hy = r / g.hw, hx = r - hy * g.hw;
+      const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
+      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) pp[i] = (img << 20) | (iy * g.W + ix);
+    }
+  }
+  __syncthreads();
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  // W loader: position p = i*256 + t -> tap p >> 6, row (p >> 2) & 15, physical chunk p & 3 (row-swizzled like the wide W tile)
+  auto issue = [&](int cc) {
+    const int which = cc >= c0chunks ? 1 : 0;
+    const T* src = reinterpret_cast<const T*>(which ? a.src1 : a.src0);
+    const int ld = which ? a.ld1 : a.ld0;
+    const int coff = (which ? cc - c0chunks : cc) * BKE + xlx * EPC;
+    char* xs = smem + (cc & 1) * Cfg::XBUF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      int pk = pp[i];
+      asm volatile("" : "+v"(pk));
+      const int base = pk < 0 ? -1 : tbl[4 * (pk >> 20) + which];
+      const size_t e = (size_t)(base < 0 ? 0 : base + (pk & 0xFFFFF)) * ld + coff;
+      const char* gp = base < 0 ? zero : reinterpret_cast<const char*>(src + e);
+      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
+    }
+    char* ws = Wl + (cc & 1) * Cfg::WBUF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = i * NT + t;
+      const int tap = p >> 6, row = (p >> 2) & 15;
+      const bool ok = tap < 9;
+      const T* wp = reinterpret_cast<const T*>(a.W) + (size_t)row * a.Ktot + (size_t)(ok ? tap : 0) * Ctot + cc * BKE + ((p & 3) ^ swz64(row)) * EPC;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const char*>(wp) : zero), (lptr_t)(ws + i * (NT * 16)), 16, 0, 0);
+    }
+  };
+  // fragment addresses: this wave's 64 pixels = pixel fragments 4*wave .. 4*wave+3 of the patch
+  const int xl = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64 + lq * 16;
+  int joff[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int p = wave * 64 + j * 16;
+    const int img = p >> (g.ltw + g.lth), py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
+    joff[j] = __builtin_amdgcn_readfirstlane((img * g.hp + py * g.hw + px) * 64);
+  }
+  const int woff0 = lds64_off(lr, lq);
+  f32x4 acc[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int cc = 0; cc < nchunks; ++cc) {
+    hwait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                    // chunk cc is in for everyone; everyone is done with chunk cc - 1
+    if (cc + 1 < nchunks) issue(cc + 1);
+    const char* Xb = smem + (cc & 1) * Cfg::XBUF;
+    const char* Wb = Wl + (cc & 1) * Cfg::WBUF;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int tapoff = (ky * g.hw + kx) * 64;
+      const chunk16 wf = *reinterpret_cast<const chunk16*>(Wb + tap * 1024 + woff0);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const chunk16 xf = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[j]) + xl);
+        acc[j] = Mma<T>::run(wf, xf, acc[j]);
+      }
+    }
+  }
+  // epilogue: lane holds couts 4 lq + r of pixel lr of fragment j
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int p = wave * 64 + j * 16 + lr;
+    const int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
+    if (n >= g.n_img) continue;
+    const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
+    const size_t o = ((size_t)n * HW + (ty * th + py) * g.W + tx * tw + px) * a.out_ld;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = lq * 4 + r;
+      if (c < a.Cout) store_as(a.out, o + c, a.out_dtype, acc[j][r] + (a.bias ? a.bias[c] : 0.f));
+    }
+  }
+}
+
+// plain bias-only 3x3 stride-1 conv with at most 16 output channels on a power-of-two image of at least 16x16
+bool dc_conv3_thin_applicable(const IgemmArgs& a, int dtype) {
+  static const bool off = getenv("DCAMD_NO_THIN") != nullptr;
+  if (off || a.taps != 9 || a.stride != 1 || a.upsample || a.act != DC_ACT_NONE || a.gate || a.rowvec || a.residual || a.gn_scale || a.src2) return false;
+  if (a.Cout > 16) return false;
+  const int H = a.Hin, W = a.Win;
+  if (H < 16 || W < 16 || (H & (H - 1)) || (W & (W - 1))) return false;
+  if ((long long)a.M >= (1LL << 31)) return false;
+  const int bke = 64 / dc_dtype_size(dtype);
+  return a.C0 % bke == 0 && a.C1 % bke == 0;
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // true when the halo kernel can take this problem (3x3 stride 1, pow-2 extents >= 8, no activation / gate)
@@ -411,4 +555,35 @@ int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s
   if (dtype == DC_BF16) return launch_halo<__bf16, 4>(a, n_img, s);
   if (dtype == DC_F16) return launch_halo<_Float16, 4>(a, n_img, s);
   return launch_halo<float, 4>(a, n_img, s);
+}
+
+template <typename T>
+static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
+  static bool attr_done = false;
+  auto kern = conv3_thin_kernel<T>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ThinCfg::LDS);
+    attr_done = true;
+  }
+  IgemmArgs a = a0;
+  HaloGeom g;
+  g.H = a.Hin; g.W = a.Win; g.n_img = n_img;
+  const int tw = g.W < 32 ? g.W : 32;
+  int th = 256 / tw; if (th > g.H) th = g.H;
+  const int ni = 256 / (tw * th);
+  g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
+  g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
+  g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
+  g.nxl = (g.HR * 4 + ThinCfg::NT - 1) / ThinCfg::NT;
+  if (g.nxl > ThinCfg::NXL) { dc_set_error("conv3_thin: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
+  const long long nblk = (long long)((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_thin: bad grid %lld", nblk); return DC_ERR_SHAPE; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(ThinCfg::NT), ThinCfg::LDS, s, a, g);
+  return dc_check_launch("dc_igemm(conv3_thin)");
+}
+
+int dc_conv3_thin_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s) {
+  if (dtype == DC_BF16) return launch_thin<__bf16>(a, n_img, s);
+  if (dtype == DC_F16) return launch_thin<_Float16>(a, n_img, s);
+  return launch_thin<float>(a, n_img, s);
 }

@@ -280,8 +280,10 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   // short-K GEMMs: the activation-stationary kernel wins for GEGLU (448 vs 376 TFLOP/s at K = 256, 584 vs 544 at K = 512);
   // for plain epilogues the 256x256 tile is faster where it applies (q/k/v 505-709 vs 478-556), xreg elsewhere
   const bool use_xreg = bn == 128 && dc_igemm_xreg_applicable(a, p->dtype) && (p->act == DC_ACT_GEGLU || dc_igemm_pipe_shape(a) != 2);
+  const bool thin = !env_v1 && dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;
   if (variant) {
     static thread_local char name[64];
+    if (thin) { snprintf(name, sizeof(name), "conv3_thin<%s>", dn); *variant = name; return DC_OK; }
     if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && use_xreg) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
     else if (bn == 128 && !use_v1) {
@@ -292,6 +294,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     *variant = name;
     return DC_OK;
   }
+  if (thin) return dc_conv3_thin_launch(a, p->dtype, p->n_img, s);
   if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) return dc_conv3_halo_launch(a, p->dtype, p->n_img, s);
   if (bn == 128 && !use_v1 && use_xreg) return dc_igemm_xreg_launch(a, p->dtype, s);
   if (bn == 128 && !use_v1) return dc_igemm_launch_pipe(a, p->dtype, s);

@@ -146,3 +146,6 @@ int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s
 // igemm_xreg.hip: activation-stationary GEMM for K <= 256 (16-bit, 1 tap)
 bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype);
 int dc_igemm_xreg_launch(const IgemmArgs& a, int dtype, hipStream_t s);
+// conv3_halo.hip: thin-output 3x3 conv (Cout <= 16, bias only)
+bool dc_conv3_thin_applicable(const IgemmArgs& a, int dtype);
+int dc_conv3_thin_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);

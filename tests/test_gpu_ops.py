@@ -44,7 +44,7 @@ def run_igemm(**kw):
 
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
-@pytest.mark.parametrize("case", ["plain", "stride2", "upsample", "concat", "maps", "small_n", "ragged_m", "side", "side_maps"])
+@pytest.mark.parametrize("case", ["plain", "stride2", "upsample", "concat", "maps", "small_n", "ragged_m", "side", "side_maps", "thin"])
 def test_conv3x3(dt, case):
     torch.manual_seed(1)
     g = E.bke(dt)
@@ -58,6 +58,8 @@ def test_conv3x3(dt, case):
         C1 = g
     if case == "small_n":
         Cout, tile_n = 3, 32
+    if case == "thin":                      # conv_out-like: Cout <= 16 on a >= 16x16 image -> conv3_thin kernel (bias only)
+        H, W, Cout, tile_n, C1 = 16, 32, 5, 32, g
     if case == "ragged_m":
         N, H, W, Cout = 5, 6, 10, 200   # M = 300 (not a tile multiple), Cout not a tile multiple
     q = lambda t: t.to(TD[dt]).float()
@@ -91,6 +93,8 @@ def test_conv3x3(dt, case):
     Ho, Wo = ref.shape[2:]
     rv = torch.randn(n_out, Cout)
     res = q(torch.randn(n_out, Cout, Ho, Wo))
+    if case == "thin":
+        rv, res = torch.zeros_like(rv), torch.zeros_like(res)
     ref = ref + rv[:, :, None, None] + res
     Wp = E.pack_conv3x3(w, dt, DEV, tile_n)
     out = torch.full((n_out, Ho, Wo, Cout), float("nan"), dtype=TD[dt], device=DEV)
@@ -98,8 +102,8 @@ def test_conv3x3(dt, case):
     bd, rvd, resd = b.to(DEV), rv.to(DEV).contiguous(), nhwc(res, dt)
     run_igemm(dtype=dt, taps=9, stride=stride, upsample=up, n_img=n_out, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo,
               src0=ptr(a0), map0=ptr(map0), C0=C0, ld0=0, src1=ptr(a1), map1=ptr(map0) if C1 else None, C1=C1, ld1=0,
-              W=ptr(Wp), Cout=Cout, tile_n=tile_n, bias=ptr(bd), rowvec=ptr(rvd), rowvec_map=None, rowvec_ld=Cout,
-              act=L.ACT_NONE, residual=ptr(resd), res_map=None, res_dtype=dt, res_ld=Cout,
+              W=ptr(Wp), Cout=Cout, tile_n=tile_n, bias=ptr(bd), rowvec=None if case == "thin" else ptr(rvd), rowvec_map=None, rowvec_ld=Cout,
+              act=L.ACT_NONE, residual=None if case == "thin" else ptr(resd), res_map=None, res_dtype=dt, res_ld=Cout,
               out=ptr(out), out_dtype=dt, out_ld=Cout,
               src2=ptr(side[0]) if side else None, W2=ptr(side[1]) if side else None, C2=side[2] if side else 0, ld2=0)
     got = out.float().cpu().permute(0, 3, 1, 2)
