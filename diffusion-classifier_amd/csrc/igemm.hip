@@ -173,6 +173,14 @@ extern "C" int32_t dc_igemm_gn_fusable(const dc_igemm_params* p) {
   return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
 }
 
+extern "C" int32_t dc_igemm_ln_ok(const dc_igemm_params* p) {
+  if (!p) return 0;
+  dc_igemm_params q = *p;
+  if (!(q.ln_eps > 0.f)) q.ln_eps = 1e-5f;
+  const char* v = nullptr;
+  return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
+}
+
 extern "C" int32_t dc_igemm_side_ok(const dc_igemm_params* p) {
   if (!p) return 0;
   dc_igemm_params q = *p;
@@ -231,6 +239,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   a.residual = p->residual; a.res_map = p->res_map; a.out = p->out;
   a.gn_scale = p->gn_scale; a.gn_shift = p->gn_shift; a.gn_silu = p->gn_silu;
   a.src2 = p->src2; a.map2 = p->map2; a.W2 = p->W2; a.C2 = p->C2; a.ld2 = p->ld2 ? p->ld2 : p->C2;
+  a.ln_eps = p->ln_eps;
   DC_REQUIRE((p->gn_scale == nullptr) == (p->gn_shift == nullptr), DC_ERR_ARG, "dc_igemm: gn_scale/gn_shift must both be set or null");
   a.C0 = p->C0; a.C1 = p->C1; a.ld0 = p->ld0 ? p->ld0 : p->C0; a.ld1 = p->ld1 ? p->ld1 : p->C1;
   a.rowvec_ld = p->rowvec_ld; a.gate_ld = p->gate_ld; a.res_dtype = p->res_dtype;
@@ -279,7 +288,13 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   }
   // short-K GEMMs: the activation-stationary kernel wins for GEGLU (448 vs 376 TFLOP/s at K = 256, 584 vs 544 at K = 512);
   // for plain epilogues the 256x256 tile is faster where it applies (q/k/v 505-709 vs 478-556), xreg elsewhere
-  const bool use_xreg = bn == 128 && dc_igemm_xreg_applicable(a, p->dtype) && (p->act == DC_ACT_GEGLU || dc_igemm_pipe_shape(a) != 2);
+  const bool ln_ok = bn == 128 && !use_v1 && !a.src1 && dc_igemm_xreg_applicable(a, p->dtype);
+  if (a.ln_eps > 0.f && !ln_ok) {
+    if (variant) { *variant = "row-layernorm-unsupported"; return DC_ERR_UNSUPPORTED; }
+    dc_set_error("dc_igemm: ln_eps given but this problem cannot take the fused row LayerNorm (see dc_igemm_ln_ok)");
+    return DC_ERR_UNSUPPORTED;
+  }
+  const bool use_xreg = bn == 128 && dc_igemm_xreg_applicable(a, p->dtype) && (p->act == DC_ACT_GEGLU || a.ln_eps > 0.f || dc_igemm_pipe_shape(a) != 2);
   const bool thin = !env_v1 && dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;
   if (variant) {
     static thread_local char name[64];

@@ -94,6 +94,48 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
   for (int j = 0; j < TM; ++j)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(xr[j][kc]));
+  // fused row LayerNorm (no affine: gamma / beta are folded into W / bias by the packer): a row's K channels sit in the four
+  // lanes lq = 0..3 of its column lr, 8 per 32-channel chunk — two-pass mean / variance in fp32, two xor-shuffles each,
+  // and the normalised row goes back into the fragment registers (rounded to T exactly where the LayerNorm kernel would)
+  if (a.ln_eps > 0.f) {
+    const float invK = 1.0f / (float)a.Ktot;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float sum = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        if (kc < kcn) {
+          float f[8];
+          chunk_to_f<T>(xr[j][kc], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += f[e];
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * invK;
+      float var = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        if (kc < kcn) {
+          float f[8];
+          chunk_to_f<T>(xr[j][kc], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) var += (f[e] - mean) * (f[e] - mean);
+        }
+      var += __shfl_xor(var, 16, 64);
+      var += __shfl_xor(var, 32, 64);
+      const float rstd = rsqrtf(var * invK + a.ln_eps);
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        if (kc < kcn) {
+          float f[8];
+          chunk_to_f<T>(xr[j][kc], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd;
+          xr[j][kc] = f_to_chunk<T>(f);
+        }
+    }
+  }
   int landed = iq;                             // that wait also covered the prologue's weight slices
 
   const uint32_t sbase = lds_addr_of(smem);

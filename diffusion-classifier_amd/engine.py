@@ -114,7 +114,7 @@ class PlanBuilder:
     # ---- ops -----------------------------------------------------------------------
     def igemm(self, name, src0, W, Cout, *, taps=1, stride=1, upsample=0, src1=None, bias=None, rowvec=None,
               act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None, gn=None,
-              side=None):
+              side=None, ln_eps=0.0):
         dom = dom or self._dom(src0, src1, rowvec, gate, residual)
         Hin, Win = (src0.H * 2, src0.W * 2) if upsample else (src0.H, src0.W)
         if taps == 9:
@@ -135,6 +135,8 @@ class PlanBuilder:
                  res_dtype=residual.dt if residual is not None else 0,
                  res_ld=residual.ld if residual is not None else 0,
                  out=out, out_dtype=out.dt, out_ld=out.ld)
+        if ln_eps:               # row LayerNorm (no affine) of the A operand inside the GEMM (dc_igemm_ln_ok)
+            f.update(ln_eps=float(ln_eps))
         if side is not None:     # (src2, W2): 1x1 side source summed into the same output (conv_shortcut folded into conv2)
             s2, W2 = side
             assert (s2.H, s2.W) == (Hout, Wout) and s2.dt == src0.dt
@@ -157,6 +159,15 @@ class PlanBuilder:
             meta["K"] = kreal + side[0].C
         self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []) + ([side[0]] if side else []), [out], meta)
         return out
+
+    def ln_ok(self, src0, Cout, act=L.ACT_NONE):
+        """Can this 1-tap GEMM normalise its input rows itself (dc_igemm_ln_ok)?"""
+        fake = 1 << 20
+        cout_out = Cout // 2 if act == L.ACT_GEGLU else Cout
+        p = L.IgemmParams(dtype=src0.dt, taps=1, stride=1, upsample=0, n_img=self.n[src0.dom], Hin=src0.H, Win=src0.W,
+                          Hout=src0.H, Wout=src0.W, src0=fake, C0=src0.C, ld0=src0.ld, W=fake, Cout=Cout, tile_n=128, act=act,
+                          out=fake, out_dtype=src0.dt, out_ld=cout_out, ln_eps=1e-5)
+        return bool(L.lib().dc_igemm_ln_ok(p))
 
     def side_ok(self, src0, s2, Cout, residual=None):
         """Can a 3x3 stride-1 conv of src0 take the 1x1 side source s2 (dc_igemm_side_ok)?"""
@@ -503,6 +514,24 @@ class UNetWeights:
                 P[key + ".conv_shortcut.wb"] = pack_matrix(ws[:, C0:], self.dt, self.dev)
         return P
 
+    def fold_layernorms(self, tb_):
+        """LayerNorm folded into the GEMM that consumes it: y = W (x_hat * g + b) + c = (W diag(g)) x_hat + (W b + c).  Packs
+        `<tb>.qkv.wf/.bf` (norm1 -> q/k/v) and `<tb>.ff.net.0.proj.wf/.bf` (norm3 -> GEGLU projection); the kernel then only
+        standardises the rows (dc_igemm ln_eps)."""
+        P, sd = self.P, self._sd
+        if tb_ + ".qkv.wf" in P:
+            return P
+        g1, b1 = sd[tb_ + ".norm1.weight"].float(), sd[tb_ + ".norm1.bias"].float()
+        qkv = torch.cat([sd[tb_ + f".attn1.to_{n}.weight"] for n in "qkv"], 0).float()
+        P[tb_ + ".qkv.wf"] = pack_matrix(qkv * g1[None, :], self.dt, self.dev)
+        P[tb_ + ".qkv.bf"] = f32c(qkv @ b1, self.dev)
+        g3, b3 = sd[tb_ + ".norm3.weight"].float(), sd[tb_ + ".norm3.bias"].float()
+        pw, pb = sd[tb_ + ".ff.net.0.proj.weight"].float(), sd[tb_ + ".ff.net.0.proj.bias"].float()
+        perm = geglu_perm(pw.shape[0] // 2)
+        P[tb_ + ".ff.net.0.proj.wf"] = pack_matrix((pw * g3[None, :])[perm], self.dt, self.dev)
+        P[tb_ + ".ff.net.0.proj.bf"] = f32c((pb + pw @ b3)[perm], self.dev)
+        return P
+
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.P.values())
 
@@ -528,6 +557,8 @@ class UNetPlan:
         fuse_gn = os.environ.get("DCAMD_GN_FUSION") is not None
         split_skips = os.environ.get("DCAMD_NO_SKIP_SPLIT") is None
         fold_short = os.environ.get("DCAMD_NO_SHORT_FOLD") is None
+        fold_ln = os.environ.get("DCAMD_NO_LN_FOLD") is None
+        fold_ln_qkv = os.environ.get("DCAMD_LN_FOLD_QKV") is not None
         cfg = model.config
         dev = device or weights.dev
         dt = weights.dt
@@ -653,14 +684,25 @@ class UNetPlan:
             tbk = key + ".transformer_blocks.0"
             h = pb.groupnorm(key + ".gn", x, pb.const(P[key + ".norm.g"]), pb.const(P[key + ".norm.b"]), G, 1e-6, False)
             h = pb.igemm(key + ".proj_in", h, pb.const(P[key + ".proj_in.w"]), Cc, bias=pb.const(P[key + ".proj_in.b"]))
-            hn = pb.layernorm(tbk + ".ln1", h, pb.const(P[tbk + ".norm1.g"]), pb.const(P[tbk + ".norm1.b"]), 1e-5)
-            qkv = pb.igemm(tbk + ".qkv", hn, pb.const(P[tbk + ".qkv.w"]), 3 * Cc)
+            # LayerNorm folded into the consuming GEMM where the activation-stationary kernel can standardise the rows itself
+            # (gamma into W's columns, beta into the bias: UNetWeights.fold_layernorms): no LayerNorm launch, no normalised tensor
+            if fold_ln_qkv and pb.ln_ok(h, 3 * Cc):      # measured: q/k/v is faster on the 256x256 tile + a LayerNorm launch (opt-in)
+                weights.fold_layernorms(tbk)
+                qkv = pb.igemm(tbk + ".qkv", h, pb.const(P[tbk + ".qkv.wf"]), 3 * Cc, bias=pb.const(P[tbk + ".qkv.bf"]), ln_eps=1e-5)
+            else:
+                hn = pb.layernorm(tbk + ".ln1", h, pb.const(P[tbk + ".norm1.g"]), pb.const(P[tbk + ".norm1.b"]), 1e-5)
+                qkv = pb.igemm(tbk + ".qkv", hn, pb.const(P[tbk + ".qkv.w"]), 3 * Cc)
             o = pb.attention(tbk + ".attn1", qkv.view(0, Cc), qkv.view(Cc, Cc), qkv.view(2 * Cc, Cc), heads)
             h = pb.igemm(tbk + ".attn_out", o, pb.const(P[tbk + ".attn1.to_out.0.w"]), Cc,
                          bias=pb.const(P[tbk + ".attn1.to_out.0.b"]), rowvec=cvec[key], residual=h)
-            hn = pb.layernorm(tbk + ".ln3", h, pb.const(P[tbk + ".norm3.g"]), pb.const(P[tbk + ".norm3.b"]), 1e-5)
-            f = pb.igemm(tbk + ".geglu", hn, pb.const(P[tbk + ".ff.net.0.proj.w"]), 8 * Cc,
-                         bias=pb.const(P[tbk + ".ff.net.0.proj.b"]), act=L.ACT_GEGLU)
+            if fold_ln and pb.ln_ok(h, 8 * Cc, L.ACT_GEGLU):
+                weights.fold_layernorms(tbk)
+                f = pb.igemm(tbk + ".geglu", h, pb.const(P[tbk + ".ff.net.0.proj.wf"]), 8 * Cc,
+                             bias=pb.const(P[tbk + ".ff.net.0.proj.bf"]), act=L.ACT_GEGLU, ln_eps=1e-5)
+            else:
+                hn = pb.layernorm(tbk + ".ln3", h, pb.const(P[tbk + ".norm3.g"]), pb.const(P[tbk + ".norm3.b"]), 1e-5)
+                f = pb.igemm(tbk + ".geglu", hn, pb.const(P[tbk + ".ff.net.0.proj.w"]), 8 * Cc,
+                             bias=pb.const(P[tbk + ".ff.net.0.proj.b"]), act=L.ACT_GEGLU)
             h = pb.igemm(tbk + ".ff_out", f, pb.const(P[tbk + ".ff.net.2.w"]), Cc, bias=pb.const(P[tbk + ".ff.net.2.b"]),
                          residual=h)
             return pb.igemm(key + ".proj_out", h, pb.const(P[key + ".proj_out.w"]), Cc, bias=pb.const(P[key + ".proj_out.b"]),

@@ -105,6 +105,10 @@ typedef struct {
    * out += sum_c A2[row, c] * W2p[co, c], A2 = src2 [*, Hout, Wout, C2] read through map2, W2p packed [Cout_pad][C2].
    * Only where dc_igemm_side_ok() says so (3x3 stride-1 halo kernel, no upsample); NULL / 0 otherwise. */
   const void* src2; const int32_t* map2; const void* W2; int32_t C2, ld2;
+  /* ln_eps > 0: each A row is LayerNorm-ed on the fly, a := (a - mean(a)) * rsqrt(var(a) + ln_eps) over its K channels, no
+   * affine (fold gamma into W's columns and beta into the bias when packing).  Only where dc_igemm_ln_ok() says so (the
+   * activation-stationary GEMM: 1 tap, one source, K <= 512, 16-bit). */
+  float ln_eps; int32_t pad4_;
 } dc_igemm_params;
 int dc_igemm(const dc_igemm_params* p, dc_stream s);
 int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
@@ -115,6 +119,8 @@ const char* dc_igemm_variant(const dc_igemm_params* p);
 int32_t dc_igemm_gn_fusable(const dc_igemm_params* p);
 /* 1 when dc_igemm can take the 1x1 side source src2 / W2 for this problem. */
 int32_t dc_igemm_side_ok(const dc_igemm_params* p);
+/* 1 when dc_igemm can take ln_eps (row LayerNorm of the A operand) for this problem. */
+int32_t dc_igemm_ln_ok(const dc_igemm_params* p);
 
 /* ---------------------------------------------------------------- norms ---------- */
 /* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.

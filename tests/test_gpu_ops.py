@@ -150,7 +150,7 @@ def test_gemm_epilogues(dt, act):
 
 
 @pytest.mark.parametrize("case", ["k256_res_rowvec", "k256_dual_maps_geglu", "k512_tail_f16_f32out", "k128_many_tiles",
-                                  "tiny_images_rowvec"])
+                                  "tiny_images_rowvec", "k256_rowln", "k512_rowln_geglu"])
 def test_gemm_activation_stationary(case):
     """igemm_xreg (K <= 512, 16-bit, >= 3 N tiles): activation rows held in registers across all N tiles.  Cases cover
     ragged M, two sources with sample maps, residual through a sample map, a row vector whose samples straddle a wave,
@@ -165,7 +165,11 @@ def test_gemm_activation_stationary(case):
         "k512_tail_f16_f32out": (5, 64, 512, 0, 648, L.ACT_NONE, True, False, False, True),
         "k128_many_tiles": (9, 50, 128, 0, 1024, L.ACT_NONE, False, True, False, False),
         "tiny_images_rowvec": (40, 16, 256, 0, 512, L.ACT_NONE, False, True, False, False),
+        # ln_eps: the GEMM standardises its input rows itself (LayerNorm folded into the consumer)
+        "k256_rowln": (6, 64, 256, 0, 768, L.ACT_NONE, False, False, False, False),
+        "k512_rowln_geglu": (5, 16, 512, 0, 1024, L.ACT_GEGLU, False, False, False, False),
     }
+    rowln = "rowln" in case
     n_out, HW, C0, C1, Nn, act, use_res, use_rv, use_maps, out32 = cfgs[case]
     n_src = 4 if use_maps else n_out
     x0 = q(torch.randn(n_src, HW, C0))
@@ -176,6 +180,9 @@ def test_gemm_activation_stationary(case):
     b = torch.randn(Nn)
     a0 = x0[m0.long()] if use_maps else x0
     a = torch.cat([a0, x1[m1.long()] if use_maps else x1], -1) if C1 else a0
+    if rowln:
+        x0 = q(x0 * 3.0 + 0.5)                                   # a mean and a scale for the kernel to remove
+        a = q(F.layer_norm(x0, (C0,), eps=1e-5))                 # what the kernel must feed the MFMAs (rounded like a LayerNorm output)
     y = a.reshape(n_out * HW, -1) @ w.t() + b
     n_ch = Nn
     if act == L.ACT_GEGLU:
@@ -204,7 +211,8 @@ def test_gemm_activation_stationary(case):
     kw = dict(dtype=dt, taps=1, stride=1, upsample=0, n_img=n_out, Hin=HW, Win=1, Hout=HW, Wout=1,
               src0=ptr(d0), map0=ptr(md0), C0=C0, ld0=0, src1=ptr(d1), map1=ptr(md1), C1=C1, ld1=0,
               W=ptr(Wp), Cout=Nn, tile_n=128, bias=ptr(bp), act=act, rowvec=ptr(rv), rowvec_map=ptr(rvm), rowvec_ld=n_ch,
-              residual=ptr(res), res_map=ptr(resm), res_dtype=dt, res_ld=n_ch, out=ptr(out), out_dtype=odt, out_ld=n_ch)
+              residual=ptr(res), res_map=ptr(resm), res_dtype=dt, res_ld=n_ch, out=ptr(out), out_dtype=odt, out_ld=n_ch,
+              ln_eps=1e-5 if rowln else 0.0)
     variant = L.lib().dc_igemm_variant(L.IgemmParams(**kw)).decode()
     assert ("xreg" in variant) == (case != "tiny_images_rowvec"), variant
     run_igemm(**kw)
