@@ -26,7 +26,7 @@ import torch.distributed as dist  # noqa: E402
 
 WORKLOADS = {
     # name: (arch kwargs fn, encoder, classes, trials, default images per GPU per step, flop/forward)
-    "cifar10-unet-10x50": ("cifar10_unet_kwargs", "nn", 10, 50, 8, 10.454e9),
+    "cifar10-unet-10x50": ("cifar10_unet_kwargs", "nn", 10, 50, 16, 10.454e9),
     "small-unet-2x8": ("small_unet_kwargs", "nn", 2, 8, 8, None),
     "chexpert256-dwt-unet-2x100": ("chexpert_dwt_unet_kwargs", "nn", 2, 100, 2, 176.47e9),
     "ipmsa5-unet-5x200": ("ipmsa5_unet_kwargs", "nn", 5, 200, 1, 634.96e9),

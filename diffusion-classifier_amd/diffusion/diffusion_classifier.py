@@ -386,10 +386,10 @@ class _HipRunner:
     def _units_per_launch(self, H, W, k):
         u = self.dc.config.units_per_launch
         if u is None:
-            # ~4M output pixel rows per launch at full resolution (measured on cfg2: 1M -> 4M = +13 %), but never fewer than 192
+            # ~8M output pixel rows per launch at full resolution (measured on cfg2: 1M -> 4M = +13 %, 4M -> 8M = +2.4 %), but never fewer than 192
             # units: the deep levels of a 256x256 UNet see only units x 64 rows, and 64-unit launches left their GEMMs at
             # 0.2-0.35 PF (IPMSA: 1.14 -> 1.27 img/s; ~200 MB of arena per unit, far inside 288 GB)
-            u = max(192, (1 << 22) // (H * W))
+            u = max(192, (1 << 23) // (H * W))
         return max(k, int(u))
 
     def _plan(self, n_bj, k):
