@@ -70,6 +70,20 @@ __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3
 __device__ __forceinline__ int lds64_off(int row, int chunk) { return row * 64 + ((chunk ^ swz64(row)) << 4); }
 
 
+// quad statistics (IgemmArgs::qstats): a wave's 128 pixels are one part of one image, or (8x8 images) two whole images
+struct HaloQs {
+  static constexpr bool on = true;
+  int nbase, ltp, n_img, tile_in_img, wm, np;
+  __device__ __forceinline__ bool whole() const { return ltp >= 7; }
+  __device__ __forceinline__ int parts() const { return np; }
+  __device__ __forceinline__ bool operator()(int half, int& n, int& part) const {
+    const int p0 = wm * 128 + half * 64;
+    n = nbase + (p0 >> ltp);
+    part = ltp >= 7 ? (tile_in_img << (ltp - 7)) + ((p0 & ((1 << ltp) - 1)) >> 7) : tile_in_img;
+    return n < n_img;
+  }
+};
+
 template <int N> __device__ __forceinline__ void hwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -328,6 +342,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // ---- epilogue: straight from the accumulators (igemm_epilogue.h: the weight rows were loaded permuted) ----
   const int nw0 = min((ng << g.lni) + ((wm * 128) >> (g.ltw + g.lth)), g.n_img - 1);
   const int nw1 = min((ng << g.lni) + ((wm * 128 + 127) >> (g.ltw + g.lth)), g.n_img - 1);
+  HaloQs qsfn;
+  qsfn.nbase = ng << g.lni; qsfn.ltp = g.ltw + g.lth; qsfn.n_img = g.n_img; qsfn.tile_in_img = ty * g.tiles_x + tx; qsfn.wm = wm;
+  qsfn.np = HW >= 128 ? HW >> 7 : 1;
   epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, [&](int j, EpiRow& r) {
     const int p = wm * 128 + j * 16 + lr;
     int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     r.samp = n;
     r.o = n * HW + rem;
     r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
-  });
+  }, EpiNoPre(), qsfn);
   DC_STAMP(7);
 }
 

@@ -181,6 +181,17 @@ extern "C" int32_t dc_igemm_ln_ok(const dc_igemm_params* p) {
   return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
 }
 
+extern "C" int32_t dc_igemm_qstats_parts(const dc_igemm_params* p) {
+  if (!p) return 0;
+  dc_igemm_params q = *p;
+  alignas(16) static float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!q.qstats) q.qstats = dummy;
+  const char* v = nullptr;
+  if (igemm_run(&q, nullptr, &v) != DC_OK) return 0;
+  const int hw = p->Hout * p->Wout;
+  return hw >= 128 ? hw / 128 : 1;          // one part per wave-sized run of 128 pixels (64-pixel images: one)
+}
+
 extern "C" int32_t dc_igemm_side_ok(const dc_igemm_params* p) {
   if (!p) return 0;
   dc_igemm_params q = *p;
@@ -239,7 +250,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   a.residual = p->residual; a.res_map = p->res_map; a.out = p->out;
   a.gn_scale = p->gn_scale; a.gn_shift = p->gn_shift; a.gn_silu = p->gn_silu;
   a.src2 = p->src2; a.map2 = p->map2; a.W2 = p->W2; a.C2 = p->C2; a.ld2 = p->ld2 ? p->ld2 : p->C2;
-  a.ln_eps = p->ln_eps;
+  a.ln_eps = p->ln_eps; a.qstats = p->qstats;
   DC_REQUIRE((p->gn_scale == nullptr) == (p->gn_shift == nullptr), DC_ERR_ARG, "dc_igemm: gn_scale/gn_shift must both be set or null");
   a.C0 = p->C0; a.C1 = p->C1; a.ld0 = p->ld0 ? p->ld0 : p->C0; a.ld1 = p->ld1 ? p->ld1 : p->C1;
   a.rowvec_ld = p->rowvec_ld; a.gate_ld = p->gate_ld; a.res_dtype = p->res_dtype;
@@ -285,6 +296,15 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     if (variant) { *variant = "gn-not-fusable"; return DC_ERR_UNSUPPORTED; }
     dc_set_error("dc_igemm: gn_scale/gn_shift given but this problem cannot take the fused GroupNorm prologue (see dc_igemm_gn_fusable)");
     return DC_ERR_UNSUPPORTED;
+  }
+  if (a.qstats) {
+    const bool thin_q = !env_v1 && dc_conv3_thin_applicable(a, p->dtype);
+    const bool qs_ok = halo_ok && !thin_q && p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0;
+    if (!qs_ok) {
+      if (variant) { *variant = "qstats-unsupported"; return DC_ERR_UNSUPPORTED; }
+      dc_set_error("dc_igemm: qstats given but this problem cannot emit quad statistics (see dc_igemm_qstats_parts)");
+      return DC_ERR_UNSUPPORTED;
+    }
   }
   // short-K GEMMs: the activation-stationary kernel wins for GEGLU (448 vs 376 TFLOP/s at K = 256, 584 vs 544 at K = 512);
   // for plain epilogues the 256x256 tile is faster where it applies (q/k/v 505-709 vs 478-556), xreg elsewhere

@@ -51,9 +51,19 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 // batch: conversions and stores, nothing left to wait for.
 struct EpiNoPre { __device__ __forceinline__ void operator()() const {} };
 
-template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn, typename PreFn = EpiNoPre>
+// quad statistics for a following GroupNorm (IgemmArgs::qstats).  QsFn::on selects the code; qsfn(half, n, part):
+// the output sample and part index of pixel fragments [4 half, 4 half + 4) of the wave (wave-uniform), false when that
+// sample does not exist; qsfn.whole(): both halves belong to the same (sample, part) and are written as one record.
+struct EpiNoQs {
+  static constexpr bool on = false;
+  __device__ __forceinline__ bool operator()(int, int&, int&) const { return false; }
+  __device__ __forceinline__ bool whole() const { return true; }
+  __device__ __forceinline__ int parts() const { return 1; }
+};
+
+template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn, typename PreFn = EpiNoPre, typename QsFn = EpiNoQs>
 __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[4][TM], int tile_n, int wn, int lq,
-                                               int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn()) {
+                                               int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn(), QsFn qsfn = QsFn()) {
   constexpr bool geglu = ACT == DC_ACT_GEGLU;
   constexpr int NK = geglu ? 1 : 2;                  // 8-channel runs per pixel
   constexpr int JB = TM;                             // pixel fragments per load batch: all of them — one exposed residual latency per tile
@@ -190,6 +200,63 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     }
   }
   DC_STAMP(5);
+  // ---- quad statistics of the values about to be stored (rounded to T as the consumer will read them): per lane the
+  // two 4-channel quads of each run, summed over the lane's pixels of each half; then over the 16 pixel lanes (lane & 15)
+  // by xor-shuffles; lanes with (lane & 15) == 0 write one 16-byte record {s0, q0, s1, q1} per run.  Fixed order: the
+  // result depends on the tile geometry only.
+  if constexpr (QsFn::on) {
+    static_assert(!QsFn::on || (TM == 8 && ACT != DC_ACT_GEGLU), "quad statistics: 128-pixel wave tiles, plain epilogue");
+    if (a.qstats) {
+      typedef __attribute__((ext_vector_type(2))) float f32x2;    // (quad 0, quad 1) of a run: v_pk_add_f32 / v_pk_fma_f32
+      f32x2 qsum[2][NK], qsq[2][NK];                   // [half][run]
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { qsum[h][k] = f32x2{0.f, 0.f}; qsq[h][k] = f32x2{0.f, 0.f}; }
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+          if (orow[j] >= 0 && con[k]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 v = {Elem<T>::to_f(Elem<T>::from_f(acc[2 * k][j][e])), Elem<T>::to_f(Elem<T>::from_f(acc[2 * k + 1][j][e]))};
+              qsum[j >> 2][k] += v;
+              qsq[j >> 2][k] += v * v;
+            }
+          }
+      const bool whole = qsfn.whole();
+      // sum over the 16 pixel lanes of a row of the wave: four DPP adds (xor 1, xor 2, half-row mirror, row mirror)
+      auto row_sum = [](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+        return v;
+      };
+      auto emit = [&](int h, const f32x2 (&sm)[NK], const f32x2 (&sq)[NK]) {
+        float r[NK][4];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { r[k][0] = row_sum(sm[k][0]); r[k][1] = row_sum(sq[k][0]); r[k][2] = row_sum(sm[k][1]); r[k][3] = row_sum(sq[k][1]); }
+        int n = 0, part = 0;
+        if ((threadIdx.x & 15) == 0 && qsfn(h, n, part)) {
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+            if (con[k])
+              *reinterpret_cast<f32x4*>(a.qstats + (((size_t)n * qsfn.parts() + part) * (a.Cout >> 2) + ((c0 + 32 * k) >> 2)) * 2) =
+                  f32x4{r[k][0], r[k][1], r[k][2], r[k][3]};
+        }
+      };
+      if (whole) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { qsum[0][k] += qsum[1][k]; qsq[0][k] += qsq[1][k]; }
+        emit(0, qsum[0], qsq[0]);
+      } else {
+        emit(0, qsum[0], qsq[0]);
+        emit(1, qsum[1], qsq[1]);
+      }
+    }
+  }
   // ---- phase B: conversions and stores only (one straight-line sequence per output type) ----
   if (a.out_dtype == DC_F32) {
 #pragma unroll

@@ -17,6 +17,7 @@ struct GnArgs {
   const void* x0; const int32_t* map0; const void* x1; const int32_t* map1;
   void* y; const float* gamma; const float* beta; float* ws;
   int C0, C1, HW, groups, silu, splits, out_dtype; float eps;
+  const float* qstats; int qparts;      // statistics formed by the producer (dc_igemm_params.qstats): no statistics sweep
 };
 
 template <typename T>
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
   float sm[EPC], sq[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
-  if (on) {
+  if (on && !a.qstats) {
     int p = pl;
     for (; p + (UNR - 1) * PL < a.HW; p += UNR * PL) {
       chunk16 c[UNR];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
     }
   }
   float* rs = red; float* rq = red + PL * C;
-  if (on) {
+  if (on && !a.qstats) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { rs[pl * C + tc * EPC + e] = sm[e]; rq[pl * C + tc * EPC + e] = sq[e]; }
   }
@@ -183,6 +184,13 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
   float mean_g = 0.f, rstd_g = 0.f;
   if (t < a.groups) {                                            // groups <= 512 (host check)
     float S = 0.f, Q = 0.f;
+    if (a.qstats) {                                              // the producer's quad records, parts in fixed order
+      const int ns = a.map0 ? a.map0[n] : n, qpg = cpg >> 2, CQ = C >> 2;
+      for (int part = 0; part < a.qparts; ++part) {
+        const float2* w = reinterpret_cast<const float2*>(a.qstats) + ((size_t)ns * a.qparts + part) * CQ + t * qpg;
+        for (int q = 0; q < qpg; ++q) { const float2 v = w[q]; S += v.x; Q += v.y; }
+      }
+    } else
     for (int l = 0; l < PL; ++l)
       for (int c = t * cpg; c < (t + 1) * cpg; ++c) { S += rs[l * C + c]; Q += rq[l * C + c]; }
     const float cnt = (float)cpg * (float)a.HW;
@@ -278,6 +286,11 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   a.x0 = p->x; a.map0 = p->map0; a.x1 = p->x1; a.map1 = p->map1; a.y = p->y; a.gamma = p->gamma; a.beta = p->beta; a.ws = p->ws;
   a.C0 = p->C; a.C1 = C1; a.HW = p->HW; a.groups = p->groups; a.silu = p->silu; a.splits = p->splits;
   a.out_dtype = p->out_dtype; a.eps = p->eps;
+  a.qstats = nullptr; a.qparts = 0;
+  if (p->qstats) {
+    DC_REQUIRE(!stats_only && C1 == 0 && p->qparts > 0 && (C / p->groups) % 4 == 0 && ((uintptr_t)p->qstats & 7) == 0, DC_ERR_ARG,
+               "dc_groupnorm: qstats needs one source, qparts > 0 and (C/groups) %% 4 == 0 (C=%d groups=%d C1=%d)", C, p->groups, C1);
+  }
   const int CP = C / epc;
   int TPR = 1; while (TPR < CP && TPR < 256) TPR <<= 1;
   const int PL = 256 / TPR;
@@ -302,6 +315,7 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   const size_t img_bytes = (size_t)p->HW * C * dc_dtype_size(p->dtype);
   static const size_t img_cap = getenv("DCAMD_GN_IMAGE_CAP") ? (size_t)atoll(getenv("DCAMD_GN_IMAGE_CAP")) : (4u << 20);
   if (!no_image && img_bytes <= img_cap && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
+    a.qstats = p->qstats; a.qparts = p->qparts;      // (larger samples: the split scheme below forms its own statistics)
     int tpr = 1; while (tpr < CP) tpr <<= 1;
     const size_t lds_img = (size_t)2 * (512 / tpr) * C * sizeof(float);
     dim3 g1((unsigned)p->n), b1(512);

@@ -41,12 +41,13 @@ def round_up(a, b):
 
 class TRef:
     """Handle of a plan tensor [n(dom), H, W, C] (NHWC) or a view of one."""
-    __slots__ = ("name", "dom", "H", "W", "C", "dt", "ld", "eoff", "base", "nbytes", "first", "last", "off", "ext")
+    __slots__ = ("name", "dom", "H", "W", "C", "dt", "ld", "eoff", "base", "nbytes", "first", "last", "off", "ext", "qs")
 
     def __init__(self, name, dom, H, W, C, dt, nbytes=0, ext=None):
         self.name, self.dom, self.H, self.W, self.C, self.dt = name, dom, H, W, C, dt
         self.ld, self.eoff, self.base = C, 0, self
         self.nbytes, self.first, self.last, self.off, self.ext = nbytes, None, None, None, ext
+        self.qs = None       # (quad-statistics tensor, parts) written by the producing conv (dc_igemm_params.qstats)
 
     def view(self, coff, C):
         v = TRef(self.name + f"[{coff}:{coff + C}]", self.dom, self.H, self.W, C, self.dt)
@@ -114,7 +115,7 @@ class PlanBuilder:
     # ---- ops -----------------------------------------------------------------------
     def igemm(self, name, src0, W, Cout, *, taps=1, stride=1, upsample=0, src1=None, bias=None, rowvec=None,
               act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None, gn=None,
-              side=None, ln_eps=0.0):
+              side=None, ln_eps=0.0, qstats=False):
         dom = dom or self._dom(src0, src1, rowvec, gate, residual)
         Hin, Win = (src0.H * 2, src0.W * 2) if upsample else (src0.H, src0.W)
         if taps == 9:
@@ -146,6 +147,17 @@ class PlanBuilder:
             f.update(gn_scale=gn[0], gn_shift=gn[1], gn_silu=int(gn[2]))
         if src1 is not None:
             assert src1.dt == src0.dt and (src1.H, src1.W) == (src0.H, src0.W)
+        qs = None
+        if qstats and L.lib().dc_igemm_qstats_parts is not None:
+            # the conv also writes (sum, sumsq) per (sample, part, channel quad) of its output: the GroupNorm that consumes the
+            # tensor then streams it once (read + write) instead of sweeping it twice
+            fake = 1 << 20
+            probe = L.IgemmParams(**{k: (fake if isinstance(v, TRef) else v) for k, v in f.items() if v is not None})
+            parts = int(L.lib().dc_igemm_qstats_parts(probe))
+            if parts > 0:
+                qs = TRef(name + ".qs", dom, 1, 1, 1, L.DC_F32, nbytes=round_up(self.n[dom] * parts * (Cout // 4) * 2 * 4, 256))
+                f.update(qstats=qs)
+                out.qs = (qs, parts)
         M = self.n[dom] * Hout * Wout
         kreal = taps * (src0.C + (src1.C if src1 is not None else 0)) if k_real is None else k_real
         es = DT_SIZE[f["dtype"]]
@@ -157,7 +169,7 @@ class PlanBuilder:
         if side is not None:
             meta["flops"] += 2.0 * M * side[0].C * Cout
             meta["K"] = kreal + side[0].C
-        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []) + ([side[0]] if side else []), [out], meta)
+        self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []) + ([side[0]] if side else []), [out] + ([qs] if qs else []), meta)
         return out
 
     def ln_ok(self, src0, Cout, act=L.ACT_NONE):
@@ -219,7 +231,11 @@ class PlanBuilder:
         f = dict(x=x0, map0=self._map(x0, dom), x1=x1, map1=self._map(x1, dom), y=out, dtype=x0.dt, out_dtype=x0.dt,
                  n=n, HW=HW, C=x0.C, C1=x1.C if x1 is not None else 0, groups=groups, silu=int(silu),
                  splits=splits, eps=eps, gamma=gamma, beta=beta, ws=ws)
-        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1], [out, ws],
+        qs = None
+        if x1 is None and x0.qs is not None and (Cc // groups) % 4 == 0 and x0.dom == dom:
+            qs = x0.qs[0]
+            f.update(qstats=qs, qparts=x0.qs[1])
+        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1, qs], [out, ws],
                    dict(name=name, family="groupnorm", flops=0.0, bytes=2.0 * n * HW * Cc * DT_SIZE[x0.dt]))
         return out
 
@@ -557,6 +573,9 @@ class UNetPlan:
         fuse_gn = os.environ.get("DCAMD_GN_FUSION") is not None
         split_skips = os.environ.get("DCAMD_NO_SKIP_SPLIT") is None
         fold_short = os.environ.get("DCAMD_NO_SHORT_FOLD") is None
+        # 3x3 convs also emit the (sum, sumsq) quad statistics of their output, so the GroupNorm that follows streams the
+        # tensor once (read + write) instead of twice + write: GroupNorm 8.3 -> ~6 ms per cfg2 step
+        use_qs = os.environ.get("DCAMD_NO_QSTATS") is None
         fold_ln = os.environ.get("DCAMD_NO_LN_FOLD") is None
         fold_ln_qkv = os.environ.get("DCAMD_LN_FOLD_QKV") is not None
         cfg = model.config
@@ -645,11 +664,11 @@ class UNetPlan:
                 ts = pb.igemm(key + ".conv1s", ys, pb.const(P[key + ".conv1.wb"]), Cout, taps=9)
                 yh = pb.groupnorm(key + ".gn1", x0, pb.const(g1[:Ca]), pb.const(b1[:Ca]), Ca // cpg, eps, True)
                 h = pb.igemm(key + ".conv1", yh, pb.const(P[key + ".conv1.wa"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
-                             rowvec=tvec, residual=ts)
+                             rowvec=tvec, residual=ts, qstats=use_qs)
             else:
                 h = pb.groupnorm(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, True, x1=x1)
                 h = pb.igemm(key + ".conv1", h, pb.const(P[key + ".conv1.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
-                             rowvec=tvec)
+                             rowvec=tvec, qstats=use_qs)
             fuse2 = fuse_gn and pb.gn_fusable(h, None, Cout)
             if fuse2:
                 aff2 = pb.groupnorm_stats(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps)
@@ -665,7 +684,7 @@ class UNetPlan:
                 ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout) if split else None
                 w2 = P[key + ".conv_shortcut.wa"] if split else P[key + ".conv_shortcut.w"]
                 return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.bs"]),
-                                residual=ss, side=(x0, pb.const(w2)))
+                                residual=ss, side=(x0, pb.const(w2)), qstats=use_qs)
             if split and key + ".conv_shortcut.w" in P:
                 ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout)
                 sc = pb.igemm(key + ".short", x0, pb.const(P[key + ".conv_shortcut.wa"]), Cout,
@@ -677,7 +696,7 @@ class UNetPlan:
                 assert x1 is None
                 sc = x0
             return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.b"]),
-                            residual=sc, gn=(aff2[0], aff2[1], True) if fuse2 else None)
+                            residual=sc, gn=(aff2[0], aff2[1], True) if fuse2 else None, qstats=use_qs)
 
         def transformer(key, x):
             Cc = x.C
@@ -737,7 +756,7 @@ class UNetPlan:
                     h = transformer(f"up_blocks.{i}.attentions.{j}", h)
             if i != nb - 1:
                 key = f"up_blocks.{i}.upsamplers.0.conv"
-                h = pb.igemm(key, h, pb.const(P[key + ".w"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]))
+                h = pb.igemm(key, h, pb.const(P[key + ".w"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]), qstats=use_qs)
         h = pb.groupnorm("conv_norm_out", h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps, True)
         pred = pb.igemm("conv_out", h, pb.const(P["conv_out.w"]), cfg.out_channels, taps=9, bias=pb.const(P["conv_out.b"]),
                         out_dt=L.DC_F32, tile_n=32 if cfg.out_channels <= 32 else 128)

@@ -109,6 +109,11 @@ typedef struct {
    * affine (fold gamma into W's columns and beta into the bias when packing).  Only where dc_igemm_ln_ok() says so (the
    * activation-stationary GEMM: 1 tap, one source, K <= 512, 16-bit). */
   float ln_eps; int32_t pad4_;
+  /* quad statistics of the OUTPUT for a following GroupNorm (dc_groupnorm_params.qstats): per output sample n, per part
+   * and per quad of 4 consecutive output channels the (sum, sum of squares) of the stored values,
+   * qstats[((n * qparts + part) * (Cout/4) + quad) * 2 + (0 | 1)], qparts = dc_igemm_qstats_parts().  The GroupNorm then
+   * streams the tensor once instead of reading it twice.  NULL otherwise. */
+  float* qstats;
 } dc_igemm_params;
 int dc_igemm(const dc_igemm_params* p, dc_stream s);
 int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
@@ -121,6 +126,9 @@ int32_t dc_igemm_gn_fusable(const dc_igemm_params* p);
 int32_t dc_igemm_side_ok(const dc_igemm_params* p);
 /* 1 when dc_igemm can take ln_eps (row LayerNorm of the A operand) for this problem. */
 int32_t dc_igemm_ln_ok(const dc_igemm_params* p);
+/* > 0: dc_igemm can emit qstats for this problem, with that many parts per sample (3x3 halo kernel, output stored in the
+ * compute type, Cout a multiple of 8); 0: it cannot. */
+int32_t dc_igemm_qstats_parts(const dc_igemm_params* p);
 
 /* ---------------------------------------------------------------- norms ---------- */
 /* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.
@@ -135,6 +143,9 @@ typedef struct {
    * out_scale[n][C+C1] = rstd*gamma and out_shift = beta - mean*rstd*gamma, which dc_igemm applies on the
    * fly (gn_scale / gn_shift) — the normalised tensor is then never written to HBM. */
   float* out_scale; float* out_shift;
+  /* statistics already formed by the producer of x (dc_igemm_params.qstats; qparts parts per sample): single source
+   * (C1 == 0), (C/groups) a multiple of 4.  The statistics sweep is skipped.  NULL / 0 otherwise. */
+  const float* qstats; int32_t qparts, pad_;
 } dc_groupnorm_params;
 int dc_groupnorm(const dc_groupnorm_params* p, dc_stream s);
 int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t splits);

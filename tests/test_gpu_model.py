@@ -103,6 +103,27 @@ def test_class_shared_skip_halves_match_the_unsplit_plan(monkeypatch):
     assert relerr(outs[0], outs[1]) < 1e-5, relerr(outs[0], outs[1])
 
 
+def test_producer_side_groupnorm_statistics_match_the_swept_plan(monkeypatch):
+    """3x3 convs hand (sum, sumsq) quad statistics of their output to the GroupNorm that follows (dc_igemm qstats), which
+    then streams the tensor once.  Same statistics up to fp32 summation order."""
+    kw = dca.cifar10_unet_kwargs()
+    torch.manual_seed(18)
+    x, lam, emb = torch.randn(3, 3, 32, 32), torch.tensor([4.0, 0.5, -6.0]), torch.randn(3, 1, 128)
+    outs, used = [], []
+    for on in (True, False):
+        if on:
+            monkeypatch.delenv("DCAMD_NO_QSTATS", raising=False)
+        else:
+            monkeypatch.setenv("DCAMD_NO_QSTATS", "1")
+        m, _ = make_pair(kw, seed=7)
+        m = m.to(DEV)
+        outs.append(m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu())
+        plan = next(iter(m._plans.values()))
+        used.append(sum(1 for (_, _, f) in plan.pb.ops if "qparts" in f))
+    assert used[0] >= 20 and used[1] == 0, used
+    assert relerr(outs[0], outs[1]) < 1e-5, relerr(outs[0], outs[1])
+
+
 def test_one_token_cross_attention_shortcut_is_exact():
     """attn2 over a single class token == to_out(to_v(ctx)) for every query (what the engine uses)."""
     kw = dca.small_unet_kwargs()

@@ -523,3 +523,56 @@ def test_conv3x3_with_fused_groupnorm_prologue(dt, concat):
     assert maxrel(got, ref) < (3e-5 if dt == L.DC_F32 else 1.5e-2), maxrel(got, ref)
     p.Hin = p.Win = p.Hout = p.Wout = 4                       # 4x4 images are not on the halo kernel: fusion must be refused
     assert lib.dc_igemm_gn_fusable(p) == 0 and lib.dc_igemm(p, L.stream_ptr()) == -6
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("shape", [(3, 8, 8, 128), (5, 16, 16, 256), (3, 32, 32, 128), (2, 64, 32, 384), (3, 8, 16, 128)])
+def test_conv3x3_quad_statistics_feed_groupnorm(dt, shape):
+    """dc_igemm qstats: per (sample, part, channel quad) sum / sumsq of the STORED output; a GroupNorm given them skips its
+    statistics sweep and must match the GroupNorm that sweeps the tensor itself."""
+    torch.manual_seed(21)
+    n, H, W, Cout = shape
+    g = E.bke(dt)
+    C0 = 2 * g
+    q = lambda t: t.to(TD[dt]).float()
+    x0 = q(torch.randn(n, C0, H, W))
+    w = q(torch.randn(Cout, C0, 3, 3) / (3 * C0 ** 0.5))
+    b = torch.randn(Cout) + 0.5
+    res = q(torch.randn(n, Cout, H, W))
+    lib = L.lib()
+    a0, resd, bd, Wp = nhwc(x0, dt), nhwc(res, dt), b.to(DEV), E.pack_conv3x3(w, dt, DEV)
+    out = torch.full((n, H, W, Cout), float("nan"), dtype=TD[dt], device=DEV)
+    kw = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=C0, W=ptr(Wp),
+              Cout=Cout, tile_n=128, bias=ptr(bd), residual=ptr(resd), res_dtype=dt, res_ld=Cout, out=ptr(out), out_dtype=dt, out_ld=Cout)
+    parts = lib.dc_igemm_qstats_parts(L.IgemmParams(**kw))
+    assert parts == max(1, H * W // 128)
+    qs = torch.full((n, parts, Cout // 4, 2), float("nan"), device=DEV)
+    run_igemm(qstats=ptr(qs), **kw)
+    out2 = torch.empty_like(out)
+    run_igemm(**dict(kw, out=ptr(out2)))
+    assert torch.equal(out, out2)                                   # the statistics do not touch the output
+    of = out.float()
+    quads = of.reshape(n, H * W, Cout // 4, 4)
+    s_ref, q_ref = quads.sum((1, 3)), (quads.double() ** 2).sum((1, 3)).float()
+    got = qs.sum(1)
+    assert torch.isfinite(qs).all()
+    assert (got[..., 0] - s_ref).abs().max().item() < 2e-3 * max(1.0, s_ref.abs().max().item())
+    assert (got[..., 1] - q_ref).abs().max().item() < 1e-4 * q_ref.abs().max().item()
+    # GroupNorm(+SiLU) from the quad statistics == GroupNorm that sweeps the tensor
+    gamma, beta = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
+    splits = lib.dc_groupnorm_splits(n, H * W, Cout)
+    ws = torch.zeros(lib.dc_groupnorm_ws_floats(n, 32, splits), device=DEV)
+    ya, yb = torch.empty_like(out), torch.empty_like(out)
+    gk = dict(x=ptr(out), dtype=dt, out_dtype=dt, n=n, HW=H * W, C=Cout, C1=0, groups=32, silu=1, splits=splits, eps=1e-5,
+              gamma=ptr(gamma), beta=ptr(beta), ws=ptr(ws))
+    L.check(lib.dc_groupnorm(L.GroupnormParams(y=ptr(ya), **gk), L.stream_ptr()), "gn")
+    L.check(lib.dc_groupnorm(L.GroupnormParams(y=ptr(yb), qstats=ptr(qs), qparts=parts, **gk), L.stream_ptr()), "gn qstats")
+    torch.cuda.synchronize()
+    ref = F.silu(F.group_norm(of.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    tol = {L.DC_F32: 2e-5, L.DC_BF16: 1e-2, L.DC_F16: 2e-3}[dt]
+    assert maxrel(yb.float(), ref) < tol, maxrel(yb.float(), ref)
+    assert maxrel(yb.float(), ya.float()) < tol
+    # refused where the halo kernel does not run (stride 2) and for a GroupNorm whose groups are not whole quads
+    p2 = L.IgemmParams(**dict(kw, stride=2, Hout=H // 2, Wout=W // 2, residual=None, qstats=ptr(qs)))
+    assert lib.dc_igemm_qstats_parts(p2) == 0 and lib.dc_igemm(p2, L.stream_ptr()) == -6
+    assert lib.dc_groupnorm(L.GroupnormParams(y=ptr(yb), qstats=ptr(qs), qparts=parts, **dict(gk, groups=Cout // 2)), L.stream_ptr()) != 0
