@@ -253,7 +253,9 @@ def test_igemm_rejects_bad_arguments():
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
 @pytest.mark.parametrize("shape", [(5, 64, 128, 0, True), (3, 16, 384, 0, False), (4, 256, 256, 128, True),
-                                   (2, 4096, 128, 0, True), (3, 16, 1024, 1024, True)])
+                                   (2, 4096, 128, 0, True), (3, 16, 1024, 1024, True),
+                                   # tiny samples: one wave per sample, register resident (gn_wave_kernel)
+                                   (6, 16, 512, 0, True), (7, 16, 256, 256, True), (5, 64, 256, 0, False), (9, 10, 64, 0, True)])
 def test_groupnorm(dt, shape):
     n, HW, C0, C1, silu = shape
     torch.manual_seed(4)
