@@ -39,7 +39,7 @@ class IgemmParams(C.Structure):
                 ("out", vp), ("out_dtype", i32), ("out_ld", i32),
                 ("gn_scale", vp), ("gn_shift", vp), ("gn_silu", i32), ("pad3_", i32),
                 ("src2", vp), ("map2", vp), ("W2", vp), ("C2", i32), ("ld2", i32),
-                ("ln_eps", f32), ("pad4_", i32), ("qstats", vp)]
+                ("ln_eps", f32), ("up4", i32), ("qstats", vp)]
 
 
 class GroupnormParams(C.Structure):
@@ -75,7 +75,7 @@ class Op(C.Structure):
 
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
-           "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_igemm_side_ok", "dc_igemm_ln_ok", "dc_igemm_qstats_parts", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
+           "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_igemm_side_ok", "dc_igemm_ln_ok", "dc_igemm_qstats_parts", "dc_igemm_up4_ok", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
            "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_run_plan", "dc_run_plan_timed"]
 
 _lib = None
@@ -117,6 +117,8 @@ def lib():
     L.dc_igemm_ln_ok.restype = C.c_int32
     L.dc_igemm_qstats_parts.argtypes = [C.POINTER(IgemmParams)]
     L.dc_igemm_qstats_parts.restype = C.c_int32
+    L.dc_igemm_up4_ok.argtypes = [C.POINTER(IgemmParams)]
+    L.dc_igemm_up4_ok.restype = C.c_int32
     L.dc_igemm_side_ok.argtypes = [C.POINTER(IgemmParams)]
     L.dc_igemm_side_ok.restype = C.c_int32
     L.dc_igemm_variant.argtypes = [C.POINTER(IgemmParams)]

@@ -73,13 +73,13 @@ __device__ __forceinline__ int lds64_off(int row, int chunk) { return row * 64 +
 // quad statistics (IgemmArgs::qstats): a wave's 128 pixels are one part of one image, or (8x8 images) two whole images
 struct HaloQs {
   static constexpr bool on = true;
-  int nbase, ltp, n_img, tile_in_img, wm, np;
+  int nbase, ltp, n_img, tile_in_img, wm, np, padd;
   __device__ __forceinline__ bool whole() const { return ltp >= 7; }
   __device__ __forceinline__ int parts() const { return np; }
   __device__ __forceinline__ bool operator()(int half, int& n, int& part) const {
     const int p0 = wm * 128 + half * 64;
     n = nbase + (p0 >> ltp);
-    part = ltp >= 7 ? (tile_in_img << (ltp - 7)) + ((p0 & ((1 << ltp) - 1)) >> 7) : tile_in_img;
+    part = padd + (ltp >= 7 ? (tile_in_img << (ltp - 7)) + ((p0 & ((1 << ltp) - 1)) >> 7) : tile_in_img);
     return n < n_img;
   }
 };
@@ -89,7 +89,11 @@ template <int N> __device__ __forceinline__ void hwait_vmcnt() { asm volatile("s
 template <int V> struct IC { static constexpr int value = V; };
 
 // GN: fused GroupNorm(+SiLU) prologue compiled in (opt-in variant; the plain kernel carries none of its code)
-template <typename T, int NW, bool GN>
+// NTAP: 9 = the 3x3 conv.  4 = one PHASE of "nearest-2x upsample, then 3x3 conv" (dc_igemm_params.up4): output pixel
+// (2y+pa, 2x+pb) only sees the 2x2 source pixels (y+pa-1+dy, x+pb-1+dx), with the 3x3 taps that fall on the same source
+// pixel summed when the weights are packed — 4 taps instead of 9, the same halo of the LOW-resolution image; the four
+// phases are four times the N tiles of the grid (g.* then describes the low-resolution image).
+template <typename T, int NW, bool GN, int NTAP = 9>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
   using Cfg = HaloCfg<NW>;
   constexpr int EPC = Elem<T>::EPC;
@@ -107,6 +111,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
   tile_of_block(a, tile_m, tile_n);
+  constexpr bool UP4 = NTAP == 4;
+  int phase = 0;
+  if (UP4) { const int tn = a.tiles_n >> 2; phase = tile_n / tn; tile_n -= phase * tn; }
+  const int pa = phase >> 1, pb = phase & 1;
   const int tx = tile_m % g.tiles_x;
   const int ty = (tile_m / g.tiles_x) % g.tiles_y;
   const int ng = tile_m / (g.tiles_x * g.tiles_y);
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // element offset of the lane's W row chunk from the tile's first row (32-bit: Cout_pad*Ktot < 2^31), recomputed at every
   // issue from an opaque copy of t (a handful of VALU per tap) instead of living in VGPRs through the tap loop
   auto issue_w = [&](int cc, int tap, int slot) {
-    const T* wb = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * 128) * a.Ktot + (size_t)tap * Ctot + (size_t)cc * BKE;   // wave-uniform
+    const T* wb = reinterpret_cast<const T*>(a.W) + (size_t)((UP4 ? phase * (a.tiles_n >> 2) : 0) + tile_n) * 128 * a.Ktot +
+                  (size_t)tap * Ctot + (size_t)cc * BKE;   // wave-uniform; up4: [phase][Cout_pad][4 taps * C]
     int tt = t;
     asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // W(s) sits in ring slot s % WR, prefetch distance PD; X(cc+1) is issued at tap 0 behind W(s+PD). ----
   issue_x(0);
 #pragma unroll
-  for (int i = 0; i < PD; ++i) issue_w(0, i, i);     // a chunk has 9 taps >= PD
+  for (int i = 0; i < PD; ++i) issue_w(0, i, i);     // a chunk has NTAP taps >= PD
   if (gn) {                                          // chunk 0: transform before the first tap
     hwait_vmcnt<PD * WLD>();                         // own X(0) loads have landed (the W groups may stay in flight)
 #pragma unroll
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     // 1x1 side source, whose W2 tiles simply continue the W stream (s >= NS)
     const bool side_next = cc + 1 == nchunks && nx > 0;
     const bool has_next = cc + 1 < nchunks || side_next;
-    const int s0 = cc * 9;
+    const int s0 = cc * NTAP;
     const char* Xb = smem + (cc & 1) * Cfg::XBUF;
     auto step = [&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
@@ -296,27 +305,27 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
         if (tap >= 1 && tap <= PD) hwait_vmcnt<FLY + NXL>();
         else hwait_vmcnt<FLY>();
       } else {
-        constexpr int left = 8 - tap;               // W groups behind this one
+        constexpr int left = NTAP - 1 - tap;        // W groups behind this one
         hwait_vmcnt<(left < PD - 1 ? left : PD - 1) * WLD>();
       }
       if (gn && tap == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my in-place writes of this chunk are in LDS
       __builtin_amdgcn_s_barrier();
       constexpr int t2 = tap + PD;                    // the W group to issue now: s + PD
-      if (t2 < 9) issue_w(cc, t2, (s0 + t2) % WR);
-      else if (side_next) { if (t2 - 9 < nx) issue_w2(t2 - 9, (s0 + t2) % WR); }
-      else if (has_next) issue_w(cc + 1, t2 - 9, (s0 + t2) % WR);
+      if (t2 < NTAP) issue_w(cc, t2, (s0 + t2) % WR);
+      else if (side_next) { if (t2 - NTAP < nx) issue_w2(t2 - NTAP, (s0 + t2) % WR); }
+      else if (has_next) issue_w(cc + 1, t2 - NTAP, (s0 + t2) % WR);
       if (tap == 0 && has_next) issue_x(cc + 1);
 
       const char* Wst = Wring + ((s0 + tap) % WR) * HALO_WST;
-      constexpr int ky = tap / 3, kx = tap - ky * 3;
-      const int tapoff = (ky * g.hw + kx) * 64;
+      constexpr int ky = UP4 ? (tap >> 1) : tap / 3, kx = UP4 ? (tap & 1) : tap - ky * 3;
+      const int tapoff = ((ky + pa) * g.hw + kx + pb) * 64;       // pa = pb = 0 for the 3x3 conv
       mma_tap(Wst, Xb, tapoff);
       // X(cc+1) was issued at tap 0 and this lane's own pieces were waited for at tap PD+1: from then on transform
       // one piece per tap, behind this tap's MFMAs (other waves read the buffer only after the next chunk's barrier)
       if (gn && tap > PD && has_next) xform(cc + 1, tap > PD ? tap - PD - 1 : 0);
     };
-    step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{});
-    step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
+    step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
+    if constexpr (NTAP == 9) { step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{}); }
   }
 
   // ---- 1x1 side source (a ResNet's conv_shortcut folded into its conv2): nx steps of ONE tap (the centre) each.  X2(0)
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // step on the loads of the previous step are simply drained (vmcnt 0): ~2 k exposed cycles per step, against the whole
   // shortcut GEMM launch and the residual round trip this replaces. ----
   if (!gn) {
-    const int NSm = nchunks * 9;
+    const int NSm = nchunks * NTAP;
     for (int e = 0; e < nx; ++e) {
       if (e == 0 && nx >= PD) hwait_vmcnt<FLY>();      // W2(1 .. PD-1) may stay in flight; X2(0) landed long ago
       else hwait_vmcnt<0>();
@@ -345,6 +354,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   HaloQs qsfn;
   qsfn.nbase = ng << g.lni; qsfn.ltp = g.ltw + g.lth; qsfn.n_img = g.n_img; qsfn.tile_in_img = ty * g.tiles_x + tx; qsfn.wm = wm;
   qsfn.np = HW >= 128 ? HW >> 7 : 1;
+  qsfn.padd = 0;
+  if (UP4) { qsfn.padd = phase * qsfn.np; qsfn.np *= 4; }       // every phase contributes its own parts of the output sample
   epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, [&](int j, EpiRow& r) {
     const int p = wm * 128 + j * 16 + lr;
     int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
     const int rem = (ty * th + py) * g.W + tx * tw + px;
     r.samp = n;
-    r.o = n * HW + rem;
+    r.o = UP4 ? n * (4 * HW) + (2 * (ty * th + py) + pa) * (2 * g.W) + 2 * (tx * tw + px) + pb : n * HW + rem;
     r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
   }, EpiNoPre(), qsfn);
   DC_STAMP(7);
@@ -532,11 +543,12 @@ bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype) {
 }
 
 template <typename T, int NW>
-static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s) {
+static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 = false) {
   using Cfg = HaloCfg<NW>;
-  static bool attr_done_v[2] = {false, false};
-  bool& attr_done = attr_done_v[a0.gn_scale ? 1 : 0];
-  void (*kern)(const IgemmArgs, const HaloGeom) = a0.gn_scale ? conv3_halo_kernel<T, NW, true> : conv3_halo_kernel<T, NW, false>;
+  static bool attr_done_v[3] = {false, false, false};
+  bool& attr_done = attr_done_v[up4 ? 2 : (a0.gn_scale ? 1 : 0)];
+  void (*kern)(const IgemmArgs, const HaloGeom) = up4 ? conv3_halo_kernel<T, NW, false, 4>
+                                                  : (a0.gn_scale ? conv3_halo_kernel<T, NW, true> : conv3_halo_kernel<T, NW, false>);
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_done = true;
@@ -557,6 +569,33 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s) {
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
+}
+
+// "nearest-2x upsample, then 3x3 conv" as four 2x2-tap phases on the low-resolution image (a.W: the phase-summed weights
+// [4][Cout_pad][4 * C], see dc_igemm_params.up4): 4/9 of the MACs
+bool dc_conv3_up4_applicable(const IgemmArgs& a, int dtype) {
+  if (a.taps != 9 || a.stride != 1 || !a.upsample || a.act != DC_ACT_NONE || a.gate || a.gn_scale || a.src2 || a.residual) return false;
+  IgemmArgs lo = a;
+  lo.upsample = 0; lo.Hin = a.Hin >> 1; lo.Win = a.Win >> 1;
+  return dc_conv3_halo_applicable(lo, dtype);
+}
+
+int dc_conv3_up4_launch(const IgemmArgs& a0, int dtype, int n_img, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.upsample = 0; a.Hin = a0.Hin >> 1; a.Win = a0.Win >> 1;      // the kernel walks the LOW-resolution image
+  a.Ktot = 4 * (a.C0 + a.C1);
+  a.tiles_n = 4 * a0.tiles_n;                                    // phase-major N tiles
+  a.n_fast = 0;
+  static const int nw_env = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
+  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : nw_env;
+  if (nw == 8) {
+    if (dtype == DC_BF16) return launch_halo<__bf16, 8>(a, n_img, s, true);
+    if (dtype == DC_F16) return launch_halo<_Float16, 8>(a, n_img, s, true);
+    return launch_halo<float, 8>(a, n_img, s, true);
+  }
+  if (dtype == DC_BF16) return launch_halo<__bf16, 4>(a, n_img, s, true);
+  if (dtype == DC_F16) return launch_halo<_Float16, 4>(a, n_img, s, true);
+  return launch_halo<float, 4>(a, n_img, s, true);
 }
 
 int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s) {

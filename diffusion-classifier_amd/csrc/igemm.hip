@@ -189,7 +189,16 @@ extern "C" int32_t dc_igemm_qstats_parts(const dc_igemm_params* p) {
   const char* v = nullptr;
   if (igemm_run(&q, nullptr, &v) != DC_OK) return 0;
   const int hw = p->Hout * p->Wout;
+  if (p->up4) { const int lo = hw >> 2; return 4 * (lo >= 128 ? lo / 128 : 1); }     // per phase, on the low-resolution image
   return hw >= 128 ? hw / 128 : 1;          // one part per wave-sized run of 128 pixels (64-pixel images: one)
+}
+
+extern "C" int32_t dc_igemm_up4_ok(const dc_igemm_params* p) {
+  if (!p) return 0;
+  dc_igemm_params q = *p;
+  q.up4 = 1;
+  const char* v = nullptr;
+  return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
 }
 
 extern "C" int32_t dc_igemm_side_ok(const dc_igemm_params* p) {
@@ -282,6 +291,23 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   static const int halo_nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
   const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
+  // four-phase upsample conv (W in the phase-summed form): the caller opted in, so anything else is an error
+  if (p->up4) {
+    const bool up4_ok = bn == 128 && !use_v1 && !no_halo && !a.src1 && dc_conv3_up4_applicable(a, p->dtype) &&
+                        (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0));
+    if (!up4_ok) {
+      if (variant) { *variant = "up4-unsupported"; return DC_ERR_UNSUPPORTED; }
+      dc_set_error("dc_igemm: up4 given but this problem cannot take the four-phase upsample conv (see dc_igemm_up4_ok)");
+      return DC_ERR_UNSUPPORTED;
+    }
+    if (variant) {
+      static thread_local char name4[64];
+      snprintf(name4, sizeof(name4), "conv3_up4<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 16 || a.Win <= 16) ? 8 : 4);
+      *variant = name4;
+      return DC_OK;
+    }
+    return dc_conv3_up4_launch(a, p->dtype, p->n_img, s);
+  }
   if (a.src2) {
     const int bke64 = 64 / dc_dtype_size(p->dtype);
     const bool side_ok = halo_ok && !a.gn_scale && !a.upsample && a.W2 && a.C2 >= 2 * bke64 && a.C2 % bke64 == 0 && a.ld2 % epc == 0 &&

@@ -115,7 +115,7 @@ class PlanBuilder:
     # ---- ops -----------------------------------------------------------------------
     def igemm(self, name, src0, W, Cout, *, taps=1, stride=1, upsample=0, src1=None, bias=None, rowvec=None,
               act=L.ACT_NONE, gate=None, residual=None, out_dt=None, tile_n=128, wdt=None, dom=None, k_real=None, gn=None,
-              side=None, ln_eps=0.0, qstats=False):
+              side=None, ln_eps=0.0, qstats=False, up4=False):
         dom = dom or self._dom(src0, src1, rowvec, gate, residual)
         Hin, Win = (src0.H * 2, src0.W * 2) if upsample else (src0.H, src0.W)
         if taps == 9:
@@ -136,6 +136,10 @@ class PlanBuilder:
                  res_dtype=residual.dt if residual is not None else 0,
                  res_ld=residual.ld if residual is not None else 0,
                  out=out, out_dtype=out.dt, out_ld=out.ld)
+        if up4:                  # W is the four-phase form of an upsample conv's weights (pack_up4, dc_igemm_up4_ok)
+            assert upsample and taps == 9
+            f.update(up4=1)
+            k_real = 4 * src0.C
         if ln_eps:               # row LayerNorm (no affine) of the A operand inside the GEMM (dc_igemm_ln_ok)
             f.update(ln_eps=float(ln_eps))
         if side is not None:     # (src2, W2): 1x1 side source summed into the same output (conv_shortcut folded into conv2)
@@ -171,6 +175,14 @@ class PlanBuilder:
             meta["K"] = kreal + side[0].C
         self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []) + ([side[0]] if side else []), [out] + ([qs] if qs else []), meta)
         return out
+
+    def up4_ok(self, src0, Cout):
+        """Can the upsample conv of src0 run as four 2x2-tap phases on the low-resolution image (dc_igemm_up4_ok)?"""
+        fake = 1 << 20
+        p = L.IgemmParams(dtype=src0.dt, taps=9, stride=1, upsample=1, n_img=self.n[src0.dom], Hin=2 * src0.H, Win=2 * src0.W,
+                          Hout=2 * src0.H, Wout=2 * src0.W, src0=fake, C0=src0.C, ld0=src0.ld, W=fake, Cout=Cout, tile_n=128,
+                          bias=fake, out=fake, out_dtype=src0.dt, out_ld=Cout, up4=1)
+        return bool(L.lib().dc_igemm_up4_ok(p))
 
     def ln_ok(self, src0, Cout, act=L.ACT_NONE):
         """Can this 1-tap GEMM normalise its input rows itself (dc_igemm_ln_ok)?"""
@@ -413,6 +425,28 @@ def pack_conv3x3(w, dt, device, tile_n=128, kpad=None):
     return pack_matrix(m, dt, device, tile_n)
 
 
+def pack_up4(w, dt, device, tile_n=128):
+    """[Cout, Cin, 3, 3] -> [4, Cout_pad, 4*Cin]: the four-phase form of "nearest-2x upsample, then 3x3 conv"
+    (dc_igemm_params.up4).  Output pixel (2y+a, 2x+b) reads the 2x2 source pixels (y+a-1+dy, x+b-1+dx); the 3x3 taps that
+    land on the same source pixel are summed in fp32: rows a=0 -> (k0 | k1+k2), a=1 -> (k0+k1 | k2), columns alike.
+    k = (dy*2+dx)*Cin + c."""
+    w = w.detach().to(torch.float32)
+    sets = (((0,), (1, 2)), ((0, 1), (2,)))
+    phases = []
+    for a in range(2):
+        for b in range(2):
+            taps = []
+            for dy in range(2):
+                for dx in range(2):
+                    acc = 0
+                    for ky in sets[a][dy]:
+                        for kx in sets[b][dx]:
+                            acc = acc + w[:, :, ky, kx]
+                    taps.append(acc)                                  # [Cout, Cin]
+            phases.append(pack_matrix(torch.cat(taps, 1), dt, device, tile_n))
+    return torch.stack(phases).contiguous()
+
+
 def geglu_perm(n_half):
     """Row order of the packed GEGLU projection: 16-row blocks alternate value / gate halves."""
     assert n_half % 16 == 0
@@ -576,6 +610,7 @@ class UNetPlan:
         # 3x3 convs also emit the (sum, sumsq) quad statistics of their output, so the GroupNorm that follows streams the
         # tensor once (read + write) instead of twice + write: GroupNorm 8.3 -> ~6 ms per cfg2 step
         use_qs = os.environ.get("DCAMD_NO_QSTATS") is None
+        use_up4 = os.environ.get("DCAMD_NO_UP4") is None
         fold_ln = os.environ.get("DCAMD_NO_LN_FOLD") is None
         fold_ln_qkv = os.environ.get("DCAMD_LN_FOLD_QKV") is not None
         cfg = model.config
@@ -756,7 +791,13 @@ class UNetPlan:
                     h = transformer(f"up_blocks.{i}.attentions.{j}", h)
             if i != nb - 1:
                 key = f"up_blocks.{i}.upsamplers.0.conv"
-                h = pb.igemm(key, h, pb.const(P[key + ".w"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]), qstats=use_qs)
+                if use_up4 and pb.up4_ok(h, h.C):
+                    # nearest-2x upsample + 3x3 conv == four 2x2-tap convs of the low-resolution tensor (phase-summed weights): 4/9 of the MACs
+                    if key + ".w4" not in P:
+                        P[key + ".w4"] = pack_up4(weights._sd[key + ".weight"], weights.dt, weights.dev)
+                    h = pb.igemm(key, h, pb.const(P[key + ".w4"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]), qstats=use_qs, up4=True)
+                else:
+                    h = pb.igemm(key, h, pb.const(P[key + ".w"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]), qstats=use_qs)
         h = pb.groupnorm("conv_norm_out", h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps, True)
         pred = pb.igemm("conv_out", h, pb.const(P["conv_out.w"]), cfg.out_channels, taps=9, bias=pb.const(P["conv_out.b"]),
                         out_dt=L.DC_F32, tile_n=32 if cfg.out_channels <= 32 else 128)

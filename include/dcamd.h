@@ -108,7 +108,13 @@ typedef struct {
   /* ln_eps > 0: each A row is LayerNorm-ed on the fly, a := (a - mean(a)) * rsqrt(var(a) + ln_eps) over its K channels, no
    * affine (fold gamma into W's columns and beta into the bias when packing).  Only where dc_igemm_ln_ok() says so (the
    * activation-stationary GEMM: 1 tap, one source, K <= 512, 16-bit). */
-  float ln_eps; int32_t pad4_;
+  float ln_eps;
+  /* up4 = 1 (only with upsample = 1, where dc_igemm_up4_ok() says so): W holds the four-phase form of the 3x3 weights,
+   * [phase = 2a+b][Cout_pad][(dy*2+dx) * C + c], in which output pixel (2y+a, 2x+b) = sum over the 2x2 source pixels
+   * (y+a-1+dy, x+b-1+dx) — the 3x3 taps that read the same source pixel of the nearest-2x upsampled image are summed
+   * when packing (row taps: a=0 -> (k0 | k1+k2), a=1 -> (k0+k1 | k2); columns alike).  4/9 of the MACs, same result up
+   * to the rounding of the summed weights. */
+  int32_t up4;
   /* quad statistics of the OUTPUT for a following GroupNorm (dc_groupnorm_params.qstats): per output sample n, per part
    * and per quad of 4 consecutive output channels the (sum, sum of squares) of the stored values,
    * qstats[((n * qparts + part) * (Cout/4) + quad) * 2 + (0 | 1)], qparts = dc_igemm_qstats_parts().  The GroupNorm then
@@ -129,6 +135,8 @@ int32_t dc_igemm_ln_ok(const dc_igemm_params* p);
 /* > 0: dc_igemm can emit qstats for this problem, with that many parts per sample (3x3 halo kernel, output stored in the
  * compute type, Cout a multiple of 8); 0: it cannot. */
 int32_t dc_igemm_qstats_parts(const dc_igemm_params* p);
+/* 1 when dc_igemm can take up4 = 1 (four-phase upsample conv) for this problem. */
+int32_t dc_igemm_up4_ok(const dc_igemm_params* p);
 
 /* ---------------------------------------------------------------- norms ---------- */
 /* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.
