@@ -20,7 +20,11 @@ def family(kernel):
     dt = "bf16" if ("DF16b" in k or "__bf16" in k) else ("f16" if ("DF16_" in k or "_Float16" in k) else "f32")
     ints = [int(v.replace("n", "-")) for v in re.findall(r"Li(n?\d+)E", k)] or [int(v) for v in re.findall(r"[<,](-?\d+)(?=[,>])", k)]
     if "conv3_halo_kernel" in k:
+        if len(ints) > 1 and ints[1] == 4:                      # NTAP = 4: the four-phase upsample conv
+            return f"conv3_up4<{dt},{ints[0]}w>"
         return f"conv3_halo<{dt},{ints[0]}w>"
+    if "conv3_thin_kernel" in k:
+        return f"conv3_thin<{dt}>"
     if "igemm_pipe_kernel" in k:
         bm, st, nh = ints[0], ints[1], ints[2]
         return f"igemm_pipe<{dt},{bm}x{128 * nh},{st}st>"
