@@ -18,6 +18,7 @@ struct GnArgs {
   void* y; const float* gamma; const float* beta; float* ws;
   int C0, C1, HW, groups, silu, splits, out_dtype; float eps;
   const float* qstats; int qparts;      // statistics formed by the producer (dc_igemm_params.qstats): no statistics sweep
+  int wsplits;                          // partial records per sample in ws (= splits, or 1 after gn_qfold_kernel)
 };
 
 template <typename T>
@@ -73,6 +74,34 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
   }
 }
 
+// Large samples with producer statistics: fold the sample's quad records (parts x C/4 of them; 512 parts for a 256x256
+// image) into ONE (sum, sumsq) record per group in ws, in a fixed order, so that gn_apply_kernel's workgroups do not each
+// walk the whole record set.  One workgroup per sample; replaces gn_stats_kernel's sweep of the tensor.
+__global__ __launch_bounds__(256) void gn_qfold_kernel(const GnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [rows][CQ] float2
+  const int C = a.C0, CQ = C >> 2, n = blockIdx.x, t = threadIdx.x;
+  const int cols = CQ < 256 ? CQ : 256, rows = 256 / cols;
+  const int ns = a.map0 ? a.map0[n] : n;
+  const float2* w = reinterpret_cast<const float2*>(a.qstats) + (size_t)ns * a.qparts * CQ;
+  float2* r2 = reinterpret_cast<float2*>(red);
+  const int r = t / cols, c = t - r * cols;
+  if (r < rows)
+    for (int q = c; q < CQ; q += cols) {
+      float S = 0.f, Q = 0.f;
+      for (int p = r; p < a.qparts; p += rows) { const float2 v = w[(size_t)p * CQ + q]; S += v.x; Q += v.y; }
+      r2[r * CQ + q] = float2{S, Q};
+    }
+  __syncthreads();
+  const int qpg = (C / a.groups) >> 2;
+  for (int g = t; g < a.groups; g += 256) {
+    float S = 0.f, Q = 0.f;
+    for (int rr = 0; rr < rows; ++rr)
+      for (int q = g * qpg; q < (g + 1) * qpg; ++q) { const float2 v = r2[rr * CQ + q]; S += v.x; Q += v.y; }
+    float* o = a.ws + ((size_t)n * a.groups + g) * 2;
+    o[0] = S; o[1] = Q;
+  }
+}
+
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   constexpr int EPC = Elem<T>::EPC;     // input chunk elements
@@ -86,8 +115,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   const int cpg = C / a.groups;
   for (int g = t; g < a.groups; g += 256) {
     float S = 0.f, Q = 0.f;
-    for (int k = 0; k < a.splits; ++k) {
-      const float* w = a.ws + (((size_t)n * a.splits + k) * a.groups + g) * 2;
+    for (int k = 0; k < a.wsplits; ++k) {
+      const float* w = a.ws + (((size_t)n * a.wsplits + k) * a.groups + g) * 2;
       S += w[0]; Q += w[1];
     }
     const float cnt = (float)cpg * (float)a.HW;
@@ -384,7 +413,7 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   a.x0 = p->x; a.map0 = p->map0; a.x1 = p->x1; a.map1 = p->map1; a.y = p->y; a.gamma = p->gamma; a.beta = p->beta; a.ws = p->ws;
   a.C0 = p->C; a.C1 = C1; a.HW = p->HW; a.groups = p->groups; a.silu = p->silu; a.splits = p->splits;
   a.out_dtype = p->out_dtype; a.eps = p->eps;
-  a.qstats = nullptr; a.qparts = 0;
+  a.qstats = nullptr; a.qparts = 0; a.wsplits = p->splits;
   if (p->qstats) {
     DC_REQUIRE(!stats_only && C1 == 0 && p->qparts > 0 && (C / p->groups) % 4 == 0 && ((uintptr_t)p->qstats & 7) == 0, DC_ERR_ARG,
                "dc_groupnorm: qstats needs one source, qparts > 0 and (C/groups) %% 4 == 0 (C=%d groups=%d C1=%d)", C, p->groups, C1);
@@ -427,7 +456,7 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
     }
   }
   if (!no_image && img_bytes <= img_cap && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
-    a.qstats = p->qstats; a.qparts = p->qparts;      // (larger samples: the split scheme below forms its own statistics)
+    a.qstats = p->qstats; a.qparts = p->qparts;
     int tpr = 1; while (tpr < CP) tpr <<= 1;
     const size_t lds_img = (size_t)2 * (512 / tpr) * C * sizeof(float);
     dim3 g1((unsigned)p->n), b1(512);
@@ -437,14 +466,23 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
     else { dc_set_error("dc_groupnorm: dtype %d", p->dtype); return DC_ERR_DTYPE; }
     return dc_check_launch("dc_groupnorm(image)");
   }
+  // large samples: split scheme; with the producer's quad statistics a small fold launch replaces the statistics sweep
+  // (the tensor is read once, not twice)
+  const bool sweep = p->qstats == nullptr;
+  if (!sweep) {
+    a.qstats = p->qstats; a.qparts = p->qparts;
+    const int CQ = C >> 2, cols = CQ < 256 ? CQ : 256;
+    hipLaunchKernelGGL(gn_qfold_kernel, dim3((unsigned)p->n), blk, (size_t)(256 / cols) * CQ * sizeof(float2), s, a);
+    a.qstats = nullptr; a.wsplits = 1;
+  }
   if (p->dtype == DC_F32) {
-    hipLaunchKernelGGL((gn_stats_kernel<float>), grid, blk, lds_stats, s, a);
+    if (sweep) hipLaunchKernelGGL((gn_stats_kernel<float>), grid, blk, lds_stats, s, a);
     hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, blk, lds_apply, s, a);
   } else if (p->dtype == DC_BF16) {
-    hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, blk, lds_stats, s, a);
+    if (sweep) hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, blk, lds_stats, s, a);
     hipLaunchKernelGGL((gn_apply_kernel<__bf16, __bf16>), grid, blk, lds_apply, s, a);
   } else if (p->dtype == DC_F16) {
-    hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, blk, lds_stats, s, a);
+    if (sweep) hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, blk, lds_stats, s, a);
     hipLaunchKernelGGL((gn_apply_kernel<_Float16, _Float16>), grid, blk, lds_apply, s, a);
   } else {
     dc_set_error("dc_groupnorm: dtype %d", p->dtype);

@@ -528,7 +528,8 @@ def test_conv3x3_with_fused_groupnorm_prologue(dt, concat):
 
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
-@pytest.mark.parametrize("shape", [(3, 8, 8, 128), (5, 16, 16, 256), (3, 32, 32, 128), (2, 64, 32, 384), (3, 8, 16, 128)])
+@pytest.mark.parametrize("shape", [(3, 8, 8, 128), (5, 16, 16, 256), (3, 32, 32, 128), (2, 64, 32, 384), (3, 8, 16, 128),
+                                   (2, 256, 128, 128)])       # > 4 MiB per sample: split GroupNorm, quad records folded by gn_qfold_kernel
 def test_conv3x3_quad_statistics_feed_groupnorm(dt, shape):
     """dc_igemm qstats: per (sample, part, channel quad) sum / sumsq of the STORED output; a GroupNorm given them skips its
     statistics sweep and must match the GroupNorm that sweeps the tensor itself."""
