@@ -78,10 +78,11 @@ extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   DC_REQUIRE(p->n > 0 && p->L > 0 && p->heads > 0, DC_ERR_SHAPE, "dc_attention: n/L/heads");
   DC_REQUIRE(p->ld_qkv >= p->heads * p->d && p->ld_out >= p->heads * p->d, DC_ERR_SHAPE, "dc_attention: ld");
   static const bool no_mfma = getenv("DCAMD_ATTN_VALU") != nullptr;
-  if (!no_mfma && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
+  static const int mfma_maxl = getenv("DCAMD_ATTN_MFMA_MAXL") ? atoi(getenv("DCAMD_ATTN_MFMA_MAXL")) : 256;
+  if (!no_mfma && p->L <= mfma_maxl && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
   static const bool force_flash = getenv("DCAMD_ATTN_FLASH") != nullptr;
   const size_t lds = (size_t)2 * p->L * p->d * sizeof(float);
-  if (!no_mfma && (lds > 160 * 1024 || force_flash) && dc_attn_flash_applicable(p->dtype, p->L, p->d))
+  if (!no_mfma && (lds > 160 * 1024 || force_flash || p->L > mfma_maxl) && dc_attn_flash_applicable(p->dtype, p->L, p->d))
     return dc_attn_flash_launch(p, reinterpret_cast<hipStream_t>(stream));
   DC_REQUIRE(lds <= 160 * 1024, DC_ERR_UNSUPPORTED,
              "dc_attention: L=%d d=%d needs %zu B of LDS (>160 KiB); long-sequence path not built yet", p->L, p->d, lds);

@@ -128,10 +128,18 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMArgs a) {
   }
 }
 
+// (sample, head) pairs per workgroup.  L == 64 (8x8 tokens), d <= 64: four pairs, one wave each, instead of four waves on
+// one pair — the four heads' 128-byte pieces of a qkv row are then fetched together (2.47 -> 2.67 TB/s on cfg2's blocks).
+static int attn_pairs_per_wg(int L, int d) {
+  static const int g64 = getenv("DCAMD_ATTN_G64") ? atoi(getenv("DCAMD_ATTN_G64")) : 4;
+  if (L == 64 && d <= 64 && (g64 == 2 || g64 == 4)) return g64;
+  return L >= 64 ? 1 : (L == 32 ? 2 : (L == 16 ? 4 : 0));
+}
+
 bool dc_attn_mfma_applicable(int dtype, int L, int d) {
   if (dtype == DC_F32) return false;
   if (L % 16 || L > 256 || d % 32 || d > 128) return false;
-  const int G = L >= 64 ? 1 : (L == 32 ? 2 : (L == 16 ? 4 : 0));
+  const int G = attn_pairs_per_wg(L, d);
   if (!G) return false;
   const int Lp = (L + 31) / 32 * 32;
   const size_t lds = (size_t)G * (L * (d + 8) + d * (Lp + 8)) * 2 + (size_t)4 * 16 * (Lp + 8) * 2;
@@ -142,7 +150,7 @@ int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s) {
   AttnMArgs a;
   a.q = p->q; a.k = p->k; a.v = p->v; a.out = p->out; a.n = p->n; a.L = p->L; a.heads = p->heads; a.d = p->d;
   a.ld_qkv = p->ld_qkv; a.ld_out = p->ld_out; a.scale = p->scale;
-  a.G = p->L >= 64 ? 1 : (p->L == 32 ? 2 : 4);
+  a.G = attn_pairs_per_wg(p->L, p->d);
   a.Lp = (p->L + 31) / 32 * 32;
   const size_t lds = (size_t)a.G * (a.L * (a.d + 8) + a.d * (a.Lp + 8)) * 2 + (size_t)4 * 16 * (a.Lp + 8) * 2;
   const long long npairs = (long long)p->n * p->heads;
