@@ -24,6 +24,9 @@ o = torch.empty(n, H, W, Co, device="cuda", dtype=torch.bfloat16)
 p = L.IgemmParams(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=x.data_ptr(), C0=Ci,
                   W=Wp.data_ptr(), Cout=Co, tile_n=128, bias=b.data_ptr(), residual=r.data_ptr() if r is not None else None,
                   res_dtype=dt, res_ld=Co, out=o.data_ptr(), out_dtype=dt, out_ld=Co)
+if os.environ.get("QS") == "1":        # also form the quad statistics (they sit inside the "epi:stores" interval)
+    qs = torch.zeros(n * lib.dc_igemm_qstats_parts(p) * (Co // 4) * 2, device="cuda")
+    p.qstats = qs.data_ptr()
 nblk = n * H * W // (256 if H > 8 else 512)
 st = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
 lib.dc_debug_set_stamps.argtypes = [ctypes.c_void_p]
