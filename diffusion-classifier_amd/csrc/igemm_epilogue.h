@@ -200,31 +200,38 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     }
   }
   DC_STAMP(5);
-  // ---- quad statistics of the values about to be stored (rounded to T as the consumer will read them): per lane the
+  // ---- quad statistics of the values about to be stored: per lane the
   // two 4-channel quads of each run, summed over the lane's pixels of each half; then over the 16 pixel lanes (lane & 15)
   // by xor-shuffles; lanes with (lane & 15) == 0 write one 16-byte record {s0, q0, s1, q1} per run.  Fixed order: the
   // result depends on the tile geometry only.
   if constexpr (QsFn::on) {
     static_assert(!QsFn::on || (TM == 8 && ACT != DC_ACT_GEGLU), "quad statistics: 128-pixel wave tiles, plain epilogue");
     if (a.qstats) {
-      typedef __attribute__((ext_vector_type(2))) float f32x2;    // (quad 0, quad 1) of a run: v_pk_add_f32 / v_pk_fma_f32
-      f32x2 qsum[2][NK], qsq[2][NK];                   // [half][run]
+      typedef __attribute__((ext_vector_type(2))) float f32x2;    // two adjacent accumulator registers: v_pk_add_f32 / v_pk_fma_f32
+      f32x2 qsum[2][NK][2], qsq[2][NK][2];             // [half][run][quad]: (even, odd) components, folded at the end
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int k = 0; k < NK; ++k) { qsum[h][k] = f32x2{0.f, 0.f}; qsq[h][k] = f32x2{0.f, 0.f}; }
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int qd = 0; qd < 2; ++qd) { qsum[h][k][qd] = f32x2{0.f, 0.f}; qsq[h][k][qd] = f32x2{0.f, 0.f}; }
+      // no per-pixel / per-run masks: a pixel is only ever invalid together with its whole sample, whose record is not
+      // written (qsfn returns false), and runs past Cout are not written either.  The fp32 values are taken BEFORE the
+      // rounding to T (the re-conversion cost as much as the sums): the statistics differ from those of the stored
+      // tensor by ~2^-9 / sqrt(count) relative, far below the 16-bit resolution of the normalised output.
+      // Operands are register pairs (c, c+1) of one accumulator fragment = one quad, so no moves are needed.
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int k = 0; k < NK; ++k)
-          if (orow[j] >= 0 && con[k]) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const f32x2 v = {Elem<T>::to_f(Elem<T>::from_f(acc[2 * k][j][e])), Elem<T>::to_f(Elem<T>::from_f(acc[2 * k + 1][j][e]))};
-              qsum[j >> 2][k] += v;
-              qsq[j >> 2][k] += v * v;
+          for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const f32x2 v = {acc[2 * k + qd][j][e], acc[2 * k + qd][j][e + 1]};
+              qsum[j >> 2][k][qd] += v;
+              qsq[j >> 2][k][qd] += v * v;
             }
-          }
       const bool whole = qsfn.whole();
       // sum over the 16 pixel lanes of a row of the wave: four DPP adds (xor 1, xor 2, half-row mirror, row mirror)
       auto row_sum = [](float v) {
@@ -234,10 +241,15 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
         return v;
       };
-      auto emit = [&](int h, const f32x2 (&sm)[NK], const f32x2 (&sq)[NK]) {
+      auto emit = [&](int h, const f32x2 (&sm)[NK][2], const f32x2 (&sq)[NK][2]) {
         float r[NK][4];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) { r[k][0] = row_sum(sm[k][0]); r[k][1] = row_sum(sq[k][0]); r[k][2] = row_sum(sm[k][1]); r[k][3] = row_sum(sq[k][1]); }
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int qd = 0; qd < 2; ++qd) {
+            r[k][2 * qd] = row_sum(sm[k][qd][0] + sm[k][qd][1]);
+            r[k][2 * qd + 1] = row_sum(sq[k][qd][0] + sq[k][qd][1]);
+          }
         int n = 0, part = 0;
         if ((threadIdx.x & 15) == 0 && qsfn(h, n, part)) {
 #pragma unroll
@@ -249,7 +261,9 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
       };
       if (whole) {
 #pragma unroll
-        for (int k = 0; k < NK; ++k) { qsum[0][k] += qsum[1][k]; qsq[0][k] += qsq[1][k]; }
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int qd = 0; qd < 2; ++qd) { qsum[0][k][qd] += qsum[1][k][qd]; qsq[0][k][qd] += qsq[1][k][qd]; }
         emit(0, qsum[0], qsq[0]);
       } else {
         emit(0, qsum[0], qsq[0]);

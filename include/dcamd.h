@@ -116,7 +116,7 @@ typedef struct {
    * to the rounding of the summed weights. */
   int32_t up4;
   /* quad statistics of the OUTPUT for a following GroupNorm (dc_groupnorm_params.qstats): per output sample n, per part
-   * and per quad of 4 consecutive output channels the (sum, sum of squares) of the stored values,
+   * and per quad of 4 consecutive output channels the (sum, sum of squares) of the output values (fp32, before the rounding to out_dtype),
    * qstats[((n * qparts + part) * (Cout/4) + quad) * 2 + (0 | 1)], qparts = dc_igemm_qstats_parts().  The GroupNorm then
    * streams the tensor once instead of reading it twice.  NULL otherwise. */
   float* qstats;

@@ -559,8 +559,10 @@ def test_conv3x3_quad_statistics_feed_groupnorm(dt, shape):
     s_ref, q_ref = quads.sum((1, 3)), (quads.double() ** 2).sum((1, 3)).float()
     got = qs.sum(1)
     assert torch.isfinite(qs).all()
+    # the sums are formed from the fp32 accumulators BEFORE the rounding to the storage type: for 16-bit outputs they differ
+    # from the sums over the stored tensor by the (zero-mean) rounding errors, ~2^-9 / sqrt(count) relative
     assert (got[..., 0] - s_ref).abs().max().item() < 2e-3 * max(1.0, s_ref.abs().max().item())
-    assert (got[..., 1] - q_ref).abs().max().item() < 1e-4 * q_ref.abs().max().item()
+    assert (got[..., 1] - q_ref).abs().max().item() < (1e-4 if dt == L.DC_F32 else 2e-3) * q_ref.abs().max().item()
     # GroupNorm(+SiLU) from the quad statistics == GroupNorm that sweeps the tensor
     gamma, beta = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
     splits = lib.dc_groupnorm_splits(n, H * W, Cout)
@@ -616,7 +618,7 @@ def test_upsample_conv_as_four_phases(dt, shape):
     tot = qs.sum(1)
     assert torch.isfinite(qs).all()
     assert (tot[..., 0] - s_ref).abs().max().item() < 2e-3 * max(1.0, s_ref.abs().max().item())
-    assert (tot[..., 1] - q_ref).abs().max().item() < 1e-4 * q_ref.abs().max().item()
+    assert (tot[..., 1] - q_ref).abs().max().item() < (1e-4 if dt == L.DC_F32 else 2e-3) * q_ref.abs().max().item()
     # 4x4 sources are not on the halo kernel: refused, and so is a residual
     p2 = L.IgemmParams(**dict(kw, Hin=8, Win=8, Hout=8, Wout=8))
     assert lib.dc_igemm_up4_ok(p2) == 0 and lib.dc_igemm(p2, L.stream_ptr()) == -6
