@@ -45,6 +45,7 @@ struct HaloGeom {
   int tiles_x, tiles_y;     // tiles per image
   int hw, hp, HR, nxl;      // halo width, halo pixels per image patch, halo rows per tile, X loads per lane
   int n_img, H, W;
+  float inv_hp, inv_hw;     // 1/hp, 1/hw: the loaders' piece -> (image, row, column) split without integer divisions
 };
 
 constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
@@ -143,8 +144,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     const int hr = (i * NT + t) >> 2;
     pp[i] = -1;
     if (i < g.nxl && hr < g.HR) {
-      const int img = hr / g.hp, r = hr - img * g.hp;
-      const int hy = r / g.hw, hx = r - hy * g.hw;
+      // hr < 2^12 and (hr + 0.5) / hp is at least 0.5 / hp away from an integer: the fp32 product floors exactly
+      const int img = (int)(((float)hr + 0.5f) * g.inv_hp), r = hr - img * g.hp;
+      const int hy = (int)(((float)r + 0.5f) * g.inv_hw), hx = r - hy * g.hw;
       const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
       // nearest-2x upsample folded into the gather: halo pixel (iy, ix) of the upsampled image reads source (iy>>1, ix>>1)
       if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
@@ -419,8 +421,9 @@ __global__ __launch_bounds__(256, 2) void conv3_thin_kernel(const IgemmArgs a, c
     const int hr = (i * NT + t) >> 2;
     pp[i] = -1;
     if (i < g.nxl && hr < g.HR) {
-      const int img = hr / g.hp, r = hr - img * g.hp;
-      const int hy = r / g.hw, hx = r - hy * g.hw;
+      // hr < 2^12 and (hr + 0.5) / hp is at least 0.5 / hp away from an integer: the fp32 product floors exactly
+      const int img = (int)(((float)hr + 0.5f) * g.inv_hp), r = hr - img * g.hp;
+      const int hy = (int)(((float)r + 0.5f) * g.inv_hw), hx = r - hy * g.hw;
       const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
       if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) pp[i] = (img << 20) | (iy * g.W + ix);
     }
@@ -562,6 +565,7 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
+  g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + Cfg::NT - 1) / Cfg::NT;
   if (g.HR > Cfg::XROWS || g.nxl > Cfg::NXL || g.nxl < 3) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
@@ -630,6 +634,7 @@ static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
+  g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + ThinCfg::NT - 1) / ThinCfg::NT;
   if (g.nxl > ThinCfg::NXL) { dc_set_error("conv3_thin: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   const long long nblk = (long long)((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
