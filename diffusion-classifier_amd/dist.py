@@ -30,7 +30,8 @@ def stage_pairs(stage_start, stage_end, BS):
 
 def local_pairs(stage_start, stage_end, BS, rank, world_size):
     """Pairs of the stage owned by `rank`."""
-    return stage_pairs(stage_start, stage_end, BS)[rank::world_size]
+    P = (stage_end - stage_start) * BS
+    return [(stage_start + g // BS, g % BS) for g in range(rank, P, world_size)]     # == stage_pairs(...)[rank::world_size]
 
 
 def slab_len(stage_start, stage_end, BS, world_size):
@@ -46,20 +47,16 @@ def gather_stage_errors(errors, stage_start, stage_end, rank, world_size, group=
         return errors
     BS, ncls = errors.shape[0], errors.shape[1]
     n = slab_len(stage_start, stage_end, BS, world_size)
-    mine = local_pairs(stage_start, stage_end, BS, rank, world_size)
-    slab = torch.full((n, ncls), float("inf"), dtype=errors.dtype, device=errors.device)
-    if mine:
-        jj = torch.tensor([p[0] for p in mine], device=errors.device)
-        bb = torch.tensor([p[1] for p in mine], device=errors.device)
-        slab[: len(mine)] = errors[bb, :, jj]
-    flat = torch.empty((world_size * n, ncls), dtype=errors.dtype, device=errors.device)   # dim-0 concatenation (gloo needs this form)
+    P = (stage_end - stage_start) * BS
+    dev = errors.device
+    # pair g = (j - stage_start) * BS + b lives on rank g % world, row g // world of that rank's slab: index arithmetic on
+    # the device instead of Python lists of pairs (6400 pairs x 8 ranks per call at N = 8 sat on the critical path)
+    g_mine = torch.arange(rank, P, world_size, device=dev)
+    slab = torch.full((n, ncls), float("inf"), dtype=errors.dtype, device=dev)
+    if g_mine.numel():
+        slab[: g_mine.numel()] = errors[g_mine % BS, :, stage_start + g_mine // BS]
+    flat = torch.empty((world_size * n, ncls), dtype=errors.dtype, device=dev)   # dim-0 concatenation (gloo needs this form)
     dist.all_gather_into_tensor(flat, slab.contiguous(), group=group)
-    out = flat.view(world_size, n, ncls)
-    allp = stage_pairs(stage_start, stage_end, BS)
-    for r in range(world_size):
-        pr = allp[r::world_size]
-        if pr:
-            jj = torch.tensor([p[0] for p in pr], device=errors.device)
-            bb = torch.tensor([p[1] for p in pr], device=errors.device)
-            errors[bb, :, jj] = out[r, : len(pr)]
+    g = torch.arange(P, device=dev)
+    errors[g % BS, :, stage_start + g // BS] = flat[(g % world_size) * n + g // world_size]
     return errors
