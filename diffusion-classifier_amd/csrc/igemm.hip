@@ -293,20 +293,27 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
   // four-phase upsample conv (W in the phase-summed form): the caller opted in, so anything else is an error
   if (p->up4) {
-    const bool up4_ok = bn == 128 && !use_v1 && !no_halo && !a.src1 && dc_conv3_up4_applicable(a, p->dtype) &&
-                        (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0));
-    if (!up4_ok) {
+    const bool up4_halo = bn == 128 && !use_v1 && !no_halo && !a.src1 && dc_conv3_up4_applicable(a, p->dtype) &&
+                          (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0));
+    // sources smaller than 8x8 (4x4 -> 8x8): the same four phases on the tap-gather kernel (no quad statistics there)
+    static const bool no_pipe_up4 = getenv("DCAMD_NO_PIPE_UP4") != nullptr;
+    const bool up4_pipe = !up4_halo && !no_pipe_up4 && bn == 128 && !use_v1 && !a.src1 && !a.qstats && p->taps == 9 && p->stride == 1 &&
+                          p->upsample && p->act == DC_ACT_NONE && !p->gate && !p->residual && !a.gn_scale && !a.src2 &&
+                          p->Hin >= 4 && p->Win >= 4 && p->Hin % 2 == 0 && p->Win % 2 == 0 && (p->Hin < 16 || p->Win < 16);
+    if (!up4_halo && !up4_pipe) {
       if (variant) { *variant = "up4-unsupported"; return DC_ERR_UNSUPPORTED; }
       dc_set_error("dc_igemm: up4 given but this problem cannot take the four-phase upsample conv (see dc_igemm_up4_ok)");
       return DC_ERR_UNSUPPORTED;
     }
     if (variant) {
       static thread_local char name4[64];
-      snprintf(name4, sizeof(name4), "conv3_up4<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 16 || a.Win <= 16) ? 8 : 4);
+      if (up4_halo) snprintf(name4, sizeof(name4), "conv3_up4<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 16 || a.Win <= 16) ? 8 : 4);
+      else snprintf(name4, sizeof(name4), "igemm_pipe_up4<%s,256x128,3st>", dn);
       *variant = name4;
       return DC_OK;
     }
-    return dc_conv3_up4_launch(a, p->dtype, p->n_img, s);
+    if (up4_halo) return dc_conv3_up4_launch(a, p->dtype, p->n_img, s);
+    return dc_igemm_launch_pipe_up4(a, p->dtype, s);
   }
   if (a.src2) {
     const int bke64 = 64 / dc_dtype_size(p->dtype);

@@ -57,6 +57,13 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
   tile_of_block(a, tile_m, tile_n);
+  // EV == 5: one phase of "nearest-2x upsample, then 3x3 conv" on the LOW-resolution image (dc_igemm_params.up4; sources too
+  // small for the halo kernel): 4 taps (dy, dx) at offsets (pa + dy, pb + dx) of the padded source, the four phases are four
+  // times the N tiles (phase-major stacked weights [4 * Cout_pad][4 * C]), output pixel (2y + pa, 2x + pb)
+  constexpr bool UP4 = EV == 5;
+  const int tile_nw = tile_n;                               // N tile of the stacked weight matrix
+  int pa = 0, pb = 0;
+  if (UP4) { const int tn = a.tiles_n >> 2, ph = tile_n / tn; tile_n -= ph * tn; pa = ph >> 1; pb = ph & 1; }
 
   const int HWo = a.Hout * a.Wout;
   const int pad = (a.taps == 9) ? 1 : 0;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     asm volatile("" ::"v"(base0[i]), "v"(base1[i]));
   }
   // weight rows enter LDS permuted (epi_wrow) so that the epilogue finds 8 consecutive couts per lane
-  const T* wbase = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * BN) * a.Ktot + lchunk * EPC;
+  const T* wbase = reinterpret_cast<const T*>(a.W) + (size_t)(tile_nw * BN) * a.Ktot + lchunk * EPC;
   int wro[WL];                                                // element offset of the W row behind LDS row lrow + RPI*i
 #pragma unroll
   for (int i = 0; i < WL; ++i) {
@@ -113,7 +120,8 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
   int pixo[4] = {-1, -1, -1, -1};
   auto set_tap = [&](int tap) {
     int ky = 0, kx = 0;
-    if (a.taps == 9) { ky = tap / 3; kx = tap - ky * 3; }
+    if (UP4) { ky = (tap >> 1) + pa; kx = (tap & 1) + pb; }
+    else if (a.taps == 9) { ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iy = iy0[i] + ky, ix = ix0[i] + kx;
@@ -267,6 +275,10 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     const int n = mm / HWo;
     r.samp = n;
     r.o = mm;
+    if (UP4) {
+      const int rem = mm - n * HWo, y = rem / a.Wout, x = rem - y * a.Wout;
+      r.o = n * (4 * HWo) + (2 * y + pa) * (2 * a.Wout) + 2 * x + pb;
+    }
     r.r = (a.residual && a.res_map) ? a.res_map[n] * HWo + (mm - n * HWo) : mm;
   };
   const int sf = min(mw0, a.M - 1) / HWo, sl = min(mw0 + 63, a.M - 1) / HWo;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
   // 128-cout tile index and half inside it
   auto epi = [&](f32x4 (&ac)[TN][TM], int tile128, int half) {
     if (EV < 0) epi_direct<T, TM>(a, ac, tile128, half, lq, sf, sl, rowfn);
-    else epi_direct_act<T, TM, (EV == 3 ? DC_ACT_GELU_TANH : (EV == 2 ? DC_ACT_GEGLU : DC_ACT_NONE)), EV == 4, false>(a, ac, tile128, half, lq, sf, sl, rowfn);
+    else epi_direct_act<T, TM, (EV == 3 ? DC_ACT_GELU_TANH : (EV == 2 ? DC_ACT_GEGLU : DC_ACT_NONE)), EV == 4, false>(a, ac, tile128, half, lq, sf, sl, rowfn);   // EV 0 / 5: plain
   };
   if (NH == 1) epi(acc[0], tile_n, wn);
   else {
@@ -322,6 +334,20 @@ int dc_igemm_pipe_shape(const IgemmArgs& a) {
       (long long)((a.M + 255) / 256) * (a.tiles_n / 2) >= wide_min_tiles) return 2;
   if (a.nk <= light_nk) return 0;
   return 1;
+}
+
+// four-phase upsample conv on the tap-gather kernel (sources smaller than 8x8): a0 as dc_igemm received it (upsampled extents)
+int dc_igemm_launch_pipe_up4(const IgemmArgs& a0, int dtype, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.upsample = 0; a.Hin = a0.Hin >> 1; a.Win = a0.Win >> 1; a.Hout = a.Hin; a.Wout = a.Win;
+  a.M = (int)((long long)a0.M >> 2);
+  a.Ktot = 4 * (a.C0 + a.C1);
+  a.nk = 4 * a.cpt;
+  a.tiles_n = 4 * a0.tiles_n;
+  a.n_fast = 0;
+  if (dtype == DC_BF16) return launch_pipe<__bf16, 256, 3, 1, 5, false>(a, s);
+  if (dtype == DC_F16) return launch_pipe<_Float16, 256, 3, 1, 5, false>(a, s);
+  return launch_pipe<float, 256, 3, 1, 5, false>(a, s);
 }
 
 int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s) {

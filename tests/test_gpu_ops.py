@@ -584,7 +584,8 @@ def test_conv3x3_quad_statistics_feed_groupnorm(dt, shape):
 
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
-@pytest.mark.parametrize("shape", [(3, 8, 8, 128), (2, 16, 16, 256), (2, 32, 32, 128), (5, 8, 16, 128), (3, 16, 8, 384), (9, 8, 8, 256)])
+@pytest.mark.parametrize("shape", [(3, 8, 8, 128), (2, 16, 16, 256), (2, 32, 32, 128), (5, 8, 16, 128), (3, 16, 8, 384), (9, 8, 8, 256),
+                                   (21, 4, 4, 256), (3, 4, 4, 128), (5, 2, 2, 128)])      # sources < 8x8: tap-gather kernel
 def test_upsample_conv_as_four_phases(dt, shape):
     """dc_igemm up4: nearest-2x upsample + 3x3 conv == four 2x2-tap convs of the low-resolution tensor with phase-summed
     weights (engine.pack_up4).  Checked against F.conv2d(F.interpolate(x)), together with the quad statistics."""
@@ -605,20 +606,24 @@ def test_upsample_conv_as_four_phases(dt, shape):
     kw = dict(dtype=dt, taps=9, stride=1, upsample=1, n_img=n, Hin=2 * H, Win=2 * W, Hout=2 * H, Wout=2 * W, src0=ptr(a0), C0=C0,
               W=ptr(W4), Cout=Cout, tile_n=128, bias=ptr(bd), out=ptr(out), out_dtype=dt, out_ld=Cout, up4=1)
     p = L.IgemmParams(**kw)
-    assert lib.dc_igemm_up4_ok(p) == 1 and lib.dc_igemm_variant(p).decode().startswith("conv3_up4<")
+    halo = H >= 8 and W >= 8
+    assert lib.dc_igemm_up4_ok(p) == 1
+    assert lib.dc_igemm_variant(p).decode().startswith("conv3_up4<" if halo else "igemm_pipe_up4<")
     parts = lib.dc_igemm_qstats_parts(p)
-    assert parts == 4 * max(1, H * W // 128)
-    qs = torch.full((n, parts, Cout // 4, 2), float("nan"), device=DEV)
-    run_igemm(qstats=ptr(qs), **kw)
+    assert parts == (4 * max(1, H * W // 128) if halo else 0)     # the tap-gather kernel forms no quad statistics
+    qs = torch.full((n, max(parts, 1), Cout // 4, 2), float("nan"), device=DEV)
+    run_igemm(**(dict(kw, qstats=ptr(qs)) if halo else kw))
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     assert maxrel(got, ref) < TOL[dt], maxrel(got, ref)
+    # a residual is refused (the upsample convs of the UNets carry a bias only)
+    p2 = L.IgemmParams(**dict(kw, residual=ptr(out), res_dtype=dt, res_ld=Cout))
+    assert lib.dc_igemm_up4_ok(p2) == 0 and lib.dc_igemm(p2, L.stream_ptr()) == -6
+    if not halo:
+        return
     quads = out.float().reshape(n, 4 * H * W, Cout // 4, 4)
     s_ref, q_ref = quads.sum((1, 3)), (quads.double() ** 2).sum((1, 3)).float()
     tot = qs.sum(1)
     assert torch.isfinite(qs).all()
     assert (tot[..., 0] - s_ref).abs().max().item() < 2e-3 * max(1.0, s_ref.abs().max().item())
     assert (tot[..., 1] - q_ref).abs().max().item() < (1e-4 if dt == L.DC_F32 else 2e-3) * q_ref.abs().max().item()
-    # 4x4 sources are not on the halo kernel: refused, and so is a residual
-    p2 = L.IgemmParams(**dict(kw, Hin=8, Win=8, Hout=8, Wout=8))
-    assert lib.dc_igemm_up4_ok(p2) == 0 and lib.dc_igemm(p2, L.stream_ptr()) == -6

@@ -27,6 +27,8 @@ def family(kernel):
         return f"conv3_thin<{dt}>"
     if "igemm_pipe_kernel" in k:
         bm, st, nh = ints[0], ints[1], ints[2]
+        if len(ints) > 3 and ints[3] == 5:                      # EV = 5: four-phase upsample conv on the tap-gather kernel
+            return f"igemm_pipe_up4<{dt},{bm}x{128 * nh},{st}st>"
         return f"igemm_pipe<{dt},{bm}x{128 * nh},{st}st>"
     if "igemm_xreg_kernel" in k:
         return "igemm_xreg<bf16,96xN>" if dt == "f32" else f"igemm_xreg<{dt},96xN>"   # demangler drops the type: 16-bit only kernel
