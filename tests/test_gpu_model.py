@@ -82,6 +82,26 @@ def test_cifar_unet_forward_f32():
     assert relerr(got, ref) < 3e-5, relerr(got, ref)
 
 
+def test_cifar_unet_forward_bf16():
+    """BASELINE config-2 architecture in the bench's compute type, against the oracle with the same storage rounding: covers
+    the bf16 kernels as the bench runs them (halo / four-phase upsample convs, producer-side GroupNorm statistics, one-wave
+    GroupNorm, folded shortcuts and LayerNorm).  Tolerance: a few bf16 ulps of drift over ~60 layers."""
+    kw = dca.cifar10_unet_kwargs()
+    m, o = make_pair(kw, seed=3, lowp=True)
+    torch.manual_seed(4)
+    N = 3
+    x, lam, emb = torch.randn(N, 3, 32, 32), torch.tensor([3.0, -2.0, 7.5]), torch.randn(N, 1, 128)
+    ref = o(x, lam, encoder_hidden_states=emb)
+    m = m.to(DEV).set_compute_dtype("bf16")
+    got = m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    assert torch.isfinite(got).all()
+    assert relerr(got, ref) < 1.5e-2, relerr(got, ref)          # measured 6.7e-3 (6.5e-3 with qstats / up4 switched off)
+    plan = next(iter(m._plans.values()))
+    fams = {mt.get("family", "") for mt in plan.pb.meta}
+    assert any(f.startswith("conv3_up4<bf16") for f in fams) and any(f.startswith("igemm_pipe_up4<bf16") for f in fams), fams
+    assert sum(1 for (_, _, f) in plan.pb.ops if "qparts" in f) >= 20
+
+
 def test_class_shared_skip_halves_match_the_unsplit_plan(monkeypatch):
     """conv(cat(h, skip)) = conv_a(h) + conv_b(skip): the up-path ResNets whose skip comes from the class-shared trunk run
     the skip half (GroupNorm, 3x3 conv, 1x1 shortcut) once per pair.  Same network, different summation order only."""
