@@ -81,7 +81,7 @@ def main():
     cfg = dict(pred_param="eps", schedule="cosine", noise_d=size, image_size=size, cfg_w=0.0, ema_beta=0.999, ema_warmup=0,
                ema_update_freq=1, encoder_type=enc, classes=classes, n_stages=1, evaluation_per_stage=[T],
                n_keep_per_stage=[1], n_fast_classes=2, fast_classification=False, compute_dtype=args.dtype,
-               units_per_launch=args.units_per_launch)
+               units_per_launch=args.units_per_launch, shard_grid=world > 1)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the constructor prints the parameter count (as the reference does): stdout carries the JSON line only
         dc = dca.DiffusionClassifier(backbone, dca.Config(**cfg))

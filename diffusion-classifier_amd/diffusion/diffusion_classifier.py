@@ -6,7 +6,8 @@ Kept surface (same names, argument meaning, assertions and return types):
   .evaluate(val_dataloader, stop_idx, metrics, classification)  reference :532-578
   .encode_text_prompt / .diffuse / .logsnr_schedule_cosine(_shifted)  :83-161
 `config` is the reference's attribute bag (missing keys read as None).  Additive keys read
-here: `compute_dtype` ("bf16" default | "f16" | "f32"), `units_per_launch`, `shard_grid`.
+here: `compute_dtype` ("bf16" default | "f16" | "f32"), `units_per_launch`, `shard_grid` (opt-in: True
+shards the (trial, image) grid of ONE replicated batch over the default process group).
 
 What differs is HOW classify runs.  The reference walks a Python double loop — T trials x C
 classes sequential eager backbone calls at batch BS (:686-714).  Here the (image, trial, class)
@@ -24,6 +25,10 @@ Extra keyword-only arguments (defaults keep the reference behaviour):
   rng            "reference": draw rand(BS) / randn_like(x) per trial in the reference's order;
                  "philox":   t from the CPU generator, eps on device from Philox keyed by
                              (seed, image, trial) — no eps traffic, world-size independent
+  group          a torch.distributed process group: shard the (trial, image) grid of THIS batch over its
+                 ranks (every rank must pass the identical x; checked).  Default (None, `shard_grid`
+                 unset): no grid sharding — under `accelerate launch` each rank scores its own images,
+                 exactly like the reference (:615-617).
 """
 import math
 import os
@@ -101,7 +106,7 @@ class DiffusionClassifier(nn.Module):
     # ---- the hot path ---------------------------------------------------------------------
     @torch.no_grad()
     def classify(self, x, text=None, fast=False, *, t=None, eps=None, fast_select=None, return_errors=False,
-                 rng="reference", seed=0):
+                 rng="reference", seed=0, group=None):
         cfg = self.config
         assert self.encoder_type is not None, "Encoder must be provided for classification."
         assert len(cfg.evaluation_per_stage) == cfg.n_stages, "Number of evaluations per stage must match the number of stages."
@@ -113,7 +118,12 @@ class DiffusionClassifier(nn.Module):
         ends = [0] + list(cfg.evaluation_per_stage)
         T, ncls = ends[-1], cfg.classes
         BS = x.shape[0]
-        rank, ws = D.world() if cfg.shard_grid is not False else (0, 1)
+        # grid sharding is opt-in: the reference shards the DATALOADER over ranks, so an initialised process group alone
+        # must not make ranks mix the errors of different images
+        shard = group is not None or cfg.shard_grid is True
+        rank, ws = D.world(group) if shard else (0, 1)
+        if ws > 1:
+            D.assert_replicated(x, group)
 
         # candidate classes per image (host, exactly the reference's ops :671-679)
         if fast:
@@ -165,7 +175,7 @@ class DiffusionClassifier(nn.Module):
             pairs = D.local_pairs(ends[i], ends[i + 1], BS, rank, ws)
             runner.run_stage(pairs, classes)
             errors = runner.errors()
-            D.gather_stage_errors(errors, ends[i], ends[i + 1], rank, ws)
+            D.gather_stage_errors(errors, ends[i], ends[i + 1], rank, ws, group=group)
             errors_cpu = errors.cpu()
             # stage end: identical torch ops to the reference (:718-721), on every rank
             num_keep = cfg.n_keep_per_stage[i]
@@ -264,7 +274,11 @@ class DiffusionClassifier(nn.Module):
         metric_output = []
         if metrics is not None:
             for metric in metrics:
-                metric.sync_across_processes(None)
+                # grid sharding scores ONE replicated batch stream on all ranks: the counters are already global, summing
+                # them over ranks would multiply them by the world size.  Without it the ranks saw different images
+                # (the reference's dataloader sharding) and the counters are summed (utils/metrics.py:56-58).
+                if self.config.shard_grid is not True:
+                    metric.sync_across_processes(None)
                 metric_output.append(metric.get_output())
         if plot_function is not None and not classification:
             plot_function(output_dir=os.path.join(self.config.experiment_path, "inference_images/"), batches=batches,
@@ -278,39 +292,44 @@ class DiffusionClassifier(nn.Module):
     _CKPT_FILES = ("model", "model_1", "model_2")
 
     @staticmethod
-    def _read_state(base):
-        if os.path.exists(base + ".safetensors"):
+    def _read_state(directory, stem):
+        """`<stem>.safetensors`, or accelerate's safe_serialization=False spelling `pytorch_<stem>.bin`, under `directory`."""
+        st = os.path.join(directory, stem + ".safetensors")
+        if os.path.exists(st):
             from safetensors.torch import load_file
-            return load_file(base + ".safetensors")
-        alt = base.replace("model", "pytorch_model", 1) + ".bin"      # accelerate with safe_serialization=False
+            return load_file(st)
+        alt = os.path.join(directory, "pytorch_" + stem + ".bin")
         if os.path.exists(alt):
             return torch.load(alt, map_location="cpu", weights_only=True)
         return None
 
     def load_checkpoint(self, checkpoint_path, accelerator=None):
-        """Ingest a reference checkpoint directory.  Returns (epoch, best_metric) when experiment_state.pth exists."""
-        sd = self._read_state(os.path.join(checkpoint_path, "model"))
+        """Ingest a reference checkpoint directory (reference :769-805).  Returns the reference's triple
+        (epoch, best_metric, experiment_key); (None, None, None) when experiment_state.pth is absent."""
+        sd = self._read_state(checkpoint_path, "model")
         if sd is None:
             raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {checkpoint_path}")
         self.model.load_state_dict(sd)
-        ema_sd = self._read_state(os.path.join(checkpoint_path, "model_1"))
-        if ema_sd is not None:
-            inner = {k[len("ema_model."):]: v for k, v in ema_sd.items() if k.startswith("ema_model.")}
-            self.ema.ema_model.load_state_dict(inner)
-            for k in ("initted", "step"):
-                if k in ema_sd:
-                    getattr(self.ema, k).copy_(ema_sd[k].reshape(()))
-        else:
-            self.ema.ema_model.load_state_dict(sd)
-        enc_sd = self._read_state(os.path.join(checkpoint_path, "model_2"))
-        if enc_sd is not None and self.encoder is not None:
+        ema_sd = self._read_state(checkpoint_path, "model_1")
+        if ema_sd is None:
+            # classification always runs on the EMA copy: scoring silently with the online weights would be a wrong answer
+            raise FileNotFoundError(f"no model_1.safetensors / pytorch_model_1.bin (EMA weights) under {checkpoint_path}")
+        inner = {k[len("ema_model."):]: v for k, v in ema_sd.items() if k.startswith("ema_model.")}
+        self.ema.ema_model.load_state_dict(inner)
+        for k in ("initted", "step"):
+            if k in ema_sd:
+                getattr(self.ema, k).copy_(ema_sd[k].reshape(()))
+        enc_sd = self._read_state(checkpoint_path, "model_2")
+        if self.encoder is not None:
+            if enc_sd is None:
+                raise FileNotFoundError(f"no model_2.safetensors (class-token encoder) under {checkpoint_path}")
             self.encoder.load_state_dict(enc_sd)
         st = os.path.join(checkpoint_path, "experiment_state.pth")
         if os.path.exists(st):
             state = torch.load(st, map_location="cpu", weights_only=False)
             print(f"Checkpoint loaded. Resuming from epoch {state.get('epoch')}. Best metric {state.get('best_metric')}")
-            return state.get("epoch"), state.get("best_metric")
-        return None, None
+            return state.get("epoch"), state.get("best_metric"), state.get("experiment_key")
+        return None, None, None
 
     def save_checkpoint(self, checkpoint_dir, epoch=0, best_metric=None, experiment_key=None):
         """Write the same directory layout (used for round trips and for handing weights back to the reference)."""
@@ -396,10 +415,16 @@ class _HipRunner:
         dc, dev = self.dc, self.dev
         cfg = dc.config
         BS, Cc, H, W = self.x.shape
-        key = (BS, n_bj, k, self.dt, str(dev), (Cc, H, W), bool(getattr(self.bb, "share_trunk", True)), id(self.bb))
+        wver = getattr(self.bb, "_wver", 0)
+        key = (BS, n_bj, k, self.dt, str(dev), (Cc, H, W), bool(getattr(self.bb, "share_trunk", True)), id(self.bb),
+               self.T, cfg.classes, wver)
         sp = dc._score_plans.get(key)
         if sp is not None:
             return sp
+        # plans hold raw pointers into the packed weights they were built from: entries of an older weights version of this
+        # backbone (load_state_dict / .to() / EMA.update since) are stale — drop them so their arenas are freed
+        for old in [k_ for k_ in dc._score_plans if k_[7] == id(self.bb) and k_[10] != wver]:
+            del dc._score_plans[old]
         U, T = n_bj * k, self.T
         # one int32 control block: | pair_id (int64 x n_bj) | lam | alpha | sigma | img_of_bj | ctx_of_unit | out_index |
         words = 2 * n_bj + 4 * n_bj + 2 * U
@@ -456,7 +481,7 @@ class _HipRunner:
         # the index part of every control block (pair ids, image / class / output maps) depends on (pairs, classes) only:
         # built once and kept (stage 0 of every call sees the same pairs and the full class list); per call only the
         # three float rows (lambda, alpha, sigma of this call's t draws) are gathered.  Host time here is GPU idle time.
-        ck = (n_bj, len(pairs), pairs[0], pairs[-1], classes.numpy().tobytes())
+        ck = (n_bj, len(pairs), pairs[0], pairs[-1], T, ncls, classes.numpy().tobytes())
         cache = sp.setdefault("idx_cache", {})
         ent = cache.get(ck)
         if ent is None:

@@ -17,10 +17,26 @@ import torch
 import torch.distributed as dist
 
 
-def world():
+def world(group=None):
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+def assert_replicated(x, group=None):
+    """Grid sharding splits the (trial, image) pairs of ONE batch over the ranks: every rank must hold the same x.
+    Compares a cheap fingerprint (shape, sum, sum of squares, a strided sample) across the group."""
+    xf = x.detach().reshape(-1).to(torch.float64)
+    step = max(1, xf.numel() // 61)
+    fp = torch.cat([torch.tensor([float(x.shape[0]), float(xf.numel())], dtype=torch.float64, device=xf.device),
+                    xf.sum().reshape(1), (xf * xf).sum().reshape(1), xf[::step][:61]])
+    ws = dist.get_world_size(group)
+    allfp = torch.empty((ws * fp.numel(),), dtype=fp.dtype, device=fp.device)
+    dist.all_gather_into_tensor(allfp, fp.contiguous(), group=group)
+    allfp = allfp.view(ws, -1)
+    if not bool((allfp == allfp[0:1]).all().item()):
+        raise RuntimeError("classify(shard_grid=True / group=...) needs the identical image batch on every rank of the group; "
+                           "the ranks hold different x (dataloader-sharded launch?). Leave grid sharding off in that case.")
 
 
 def stage_pairs(stage_start, stage_end, BS):

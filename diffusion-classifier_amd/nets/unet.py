@@ -77,6 +77,7 @@ class _HipBackbone(nn.Module):
         self.share_trunk = True
         self._packed = {}
         self._plans = {}
+        self._wver = 0               # bumped whenever packed weights go stale; plan caches outside this module key on it
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
 
     def set_compute_dtype(self, name):
@@ -88,6 +89,7 @@ class _HipBackbone(nn.Module):
         """Call after mutating parameters in place (load_state_dict does it automatically)."""
         self._packed.clear()
         self._plans.clear()
+        self._wver += 1
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -103,6 +105,8 @@ class _HipBackbone(nn.Module):
         for k, v in self.__dict__.items():
             if k in ("_packed", "_plans"):
                 new.__dict__[k] = {}
+            elif k == "_wver":
+                new.__dict__[k] = 0
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new

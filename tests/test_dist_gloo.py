@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, mode="shard"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -29,14 +29,27 @@ def _worker(rank, world, port, name, q):
     import diffusion_classifier_amd as dca
     from helpers import load_case, standin_from
     g, cfg = load_case(name)
+    if mode == "shard":
+        cfg["shard_grid"] = True                         # grid sharding is opt-in
     dc = dca.DiffusionClassifier(standin_from(g, cfg), dca.Config(**cfg))
     if dc.encoder is not None:
         dc.encoder.weight.data.copy_(torch.from_numpy(g["encoder.weight"]))
     fast = bool(g["fast"])
-    out, err = dc.classify(torch.from_numpy(g["x"]), torch.from_numpy(g["labels"]) if fast else None, fast=fast,
-                           t=torch.from_numpy(g["t"]), eps=torch.from_numpy(g["eps"]),
-                           fast_select=torch.from_numpy(g["fast_select"]) if fast else None, return_errors=True)
-    q.put((rank, out.numpy(), err.numpy()))
+    x = torch.from_numpy(g["x"])
+    kw = dict(t=torch.from_numpy(g["t"]), eps=torch.from_numpy(g["eps"]),
+              fast_select=torch.from_numpy(g["fast_select"]) if fast else None, return_errors=True)
+    lab = torch.from_numpy(g["labels"]) if fast else None
+    if mode == "mismatch":
+        # an accelerate-style launch (each rank holds its own images) with grid sharding requested: must be refused
+        try:
+            dc.classify(x + rank, lab, fast=fast, group=dist.group.WORLD, **kw)
+            q.put((rank, "no error", None))
+        except RuntimeError as e:
+            q.put((rank, "refused" if "identical image batch" in str(e) else repr(e), None))
+    else:
+        # mode "off": a process group exists but sharding was not asked for -> every rank scores its whole batch alone
+        out, err = dc.classify(x, lab, fast=fast, **kw)
+        q.put((rank, out.numpy(), err.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,6 +74,33 @@ def test_sharded_classify_equals_single_process(name, world):
         fin = np.isfinite(g["errors"])
         assert np.array_equal(np.isfinite(err), fin)
         np.testing.assert_allclose(err[fin], g["errors"][fin], rtol=3e-7)   # sub-batches differ from the reference's batch of BS
+
+
+def _spawn(world, name, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_grid_sharding_is_opt_in_and_checks_that_x_is_replicated():
+    """A drop-in script launched by accelerate has a process group AND per-rank images (reference :615-617): classify must
+    not shard the grid by default, and when asked to it must refuse batches that differ across ranks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import load_case
+    g, _ = load_case("1stage_eps")
+    for rank, out, err in _spawn(2, "1stage_eps", "off"):
+        np.testing.assert_array_equal(out, g["out"])
+        np.testing.assert_array_equal(err, g["errors"])       # the full grid, computed locally, bit-equal to the reference
+    for rank, verdict, _ in _spawn(2, "1stage_eps", "mismatch"):
+        assert verdict == "refused", verdict
 
 
 def test_pair_ownership_is_a_balanced_partition():

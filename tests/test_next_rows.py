@@ -51,14 +51,35 @@ def test_checkpoint_round_trip_in_accelerate_layout(tmp_path):
     assert any(k.startswith("ema_model.") for k in keys) and "step" in keys
     dc2, _, _ = _dc()
     dc2.encoder.weight.data.zero_()
-    epoch, best = dc2.load_checkpoint(str(tmp_path))
-    assert (epoch, best) == (7, 0.9)
+    epoch, best, key = dc2.load_checkpoint(str(tmp_path))          # the reference's triple (:805)
+    assert (epoch, best, key) == (7, 0.9, None)
     for a, b in zip(dc.ema.ema_model.state_dict().values(), dc2.ema.ema_model.state_dict().values()):
         assert torch.equal(a, b)
     assert torch.equal(dc.encoder.weight, dc2.encoder.weight)
     x = torch.from_numpy(g["x"])
     t, eps = torch.from_numpy(g["t"]), torch.from_numpy(g["eps"])
     assert torch.equal(dc.classify(x, t=t, eps=eps), dc2.classify(x, t=t, eps=eps))   # inference uses the EMA copy
+
+
+def test_checkpoint_bin_spelling_and_missing_ema_are_handled(tmp_path):
+    """accelerate with safe_serialization=False writes pytorch_model*.bin; the alternate name is built from the file stem
+    only (a parent directory called `models/` must not confuse it), and a checkpoint without EMA weights is refused —
+    classification always runs on the EMA copy."""
+    from safetensors.torch import load_file
+    dc, g, cfg = _dc()
+    d = tmp_path / "models" / "ckpt"
+    dc.save_checkpoint(str(d))
+    for stem in ("model", "model_1", "model_2"):
+        sd = load_file(str(d / (stem + ".safetensors")))
+        torch.save(sd, str(d / ("pytorch_" + stem + ".bin")))
+        os.remove(d / (stem + ".safetensors"))
+    dc2, _, _ = _dc()
+    dc2.encoder.weight.data.zero_()
+    dc2.load_checkpoint(str(d))
+    assert torch.equal(dc.encoder.weight, dc2.encoder.weight)
+    os.remove(d / "pytorch_model_1.bin")
+    with pytest.raises(FileNotFoundError, match="EMA"):
+        dc2.load_checkpoint(str(d))
 
 
 def test_evaluate_and_inference_contract(tmp_path):
