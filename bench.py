@@ -5,12 +5,16 @@ A "step" = one `DiffusionClassifier.classify` call over one batch of synthetic i
 resident in HBM (BASELINE.json metric; default workload = config 2: CIFAR-10 32x32 UNet of
 reference experiments/cifar10/inference.py:94-116, 10 classes x 50 trials, bf16).
   python bench.py --gpus N --steps K --warmup W
-N>1: launched by torch.distributed.run, one rank per GPU; the (trial, image) pairs of the step
-are sharded over the ranks, one RCCL all-gather of the error slab per step (dist.py); the global
-batch grows with N (per-GPU work fixed -> "scaling": "weak").
+N>1: one rank per GPU under torch.distributed.run — either the driver launches that itself, or a plain
+`python bench.py --gpus N` starts it as a CHILD process (before this process touches the GPU) and relays its output.
+The (trial, image) pairs of the step are sharded over the ranks, one RCCL all-gather of the error slab per step
+(dist.py).  Default: the global batch grows with N (per-GPU work fixed -> "scaling": "weak"); `--global-batch B`
+fixes the total instead ("strong": what north_star quotes for CheXpert-256 1->8 GPUs).
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel family (MFMA implicit GEMM)
 timed with HIP events on the launch stream inside the last timed step; `cpu_baseline` = the
-oracle's reference-structured loop on the host cores (N=1 only, bounded sample).
+oracle's reference-structured loop on the host cores (N=1 only, bounded sample); `parity` = a small sub-grid of
+the same workload scored by the HIP path and by the CPU oracle (N=1 only, outside the timed region).
+Inputs are resident in HBM before the timed region (the H2D of x — 196 KB per cfg2 step — is not in `value`).
 """
 import argparse
 import json
@@ -48,6 +52,22 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "64"))))
 
 
+def relaunch_under_torchrun(n, argv):
+    """`python bench.py --gpus N` typed by hand: start the N ranks as a child process group and relay rank 0's line.
+    Runs before anything in this process has initialised the GPU (a process that has must never exec/replace itself)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,13 +79,20 @@ def main():
     ap.add_argument("--units-per-launch", type=int, default=None)
     ap.add_argument("--no-share-trunk", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="fix the TOTAL images per step (strong scaling) instead of images per GPU (weak, default)")
+    ap.add_argument("--stages", default=None,
+                    help="multi-stage pruning variant, e.g. '10:5,50:1' = trials-so-far:classes-kept per stage (not the BASELINE metric)")
     ap.add_argument("--breakdown", default=None, help="write the per-op event timings of the last step to this JSON file")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -78,18 +105,28 @@ def main():
     torch.manual_seed(0)
     backbone = dca.UNetCondition2D(**kw) if enc == "nn" else dca.DiT(**kw)
     size, cin = kw["sample_size"], kw["in_channels"]
+    ev, keep = [T], [1]
+    if args.stages:
+        ev, keep = zip(*[tuple(int(v) for v in st.split(":")) for st in args.stages.split(",")])
+        ev, keep, T = list(ev), list(keep), ev[-1]
     cfg = dict(pred_param="eps", schedule="cosine", noise_d=size, image_size=size, cfg_w=0.0, ema_beta=0.999, ema_warmup=0,
-               ema_update_freq=1, encoder_type=enc, classes=classes, n_stages=1, evaluation_per_stage=[T],
-               n_keep_per_stage=[1], n_fast_classes=2, fast_classification=False, compute_dtype=args.dtype,
+               ema_update_freq=1, encoder_type=enc, classes=classes, n_stages=len(ev), evaluation_per_stage=ev,
+               n_keep_per_stage=keep, n_fast_classes=2, fast_classification=False, compute_dtype=args.dtype,
                units_per_launch=args.units_per_launch, shard_grid=world > 1)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the constructor prints the parameter count (as the reference does): stdout carries the JSON line only
         dc = dca.DiffusionClassifier(backbone, dca.Config(**cfg))
     dc.ema.ema_model.share_trunk = not args.no_share_trunk
     dc = dc.to(dev)
-    B = ipg * world
+    B = args.global_batch if args.global_batch else ipg * world
     g = torch.Generator().manual_seed(0)
-    x = (torch.rand(B, cin, size, size, generator=g) * 2 - 1).to(dev)       # SURVEY §8d synthetic inputs, resident in HBM
+    dwt = "dwt" in args.workload
+    if dwt:
+        # the DWT configs score x = haar_dwt2(x0)/2 of a [-1,1] image (dataset/chexpert.py:146-147), through the HIP kernel
+        x0 = (torch.rand(B, cin // 4, 2 * size, 2 * size, generator=g) * 2 - 1).to(dev)
+        x = dca.wavelet_dec_2(x0, scale=0.5)
+    else:
+        x = (torch.rand(B, cin, size, size, generator=g) * 2 - 1).to(dev)   # SURVEY §8d synthetic inputs, resident in HBM
     torch.manual_seed(1234)
 
     def step(i):
@@ -150,6 +187,19 @@ def main():
     kernels = {k: dict(ms=round(v["ms"], 3), share=round(v["ms"] / total_ms, 4), launches=v["launches"],
                        tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) if v["flops"] else None,
                        gbps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)) for k, v in sorted(fam.items())}
+    # the Haar lifting kernel (utils/wavelet.py:4-35 replacement) on a CheXpert-shaped batch: HBM-bound, 8 bytes per input value
+    hx = torch.rand(256, 3, 256, 256, device=dev) * 2 - 1
+    dca.wavelet_dec_2(hx)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        hy = dca.wavelet_dec_2(hx, scale=0.5)
+    ev1.record()
+    torch.cuda.synchronize()
+    h_ms = ev0.elapsed_time(ev1) / 20
+    kernels["haar_dwt2"] = dict(ms=round(h_ms, 4), share=0.0, launches=1, tflops=None, gbps=round(2 * hx.numel() * 4 / h_ms / 1e6, 1),
+                                note="256x3x256x256 f32 -> 256x12x128x128, outside the timed step; peak 8000 GB/s")
+    del hx, hy
     if args.breakdown:
         rows = []
         for plan, ms in sink[:1]:
@@ -161,26 +211,77 @@ def main():
     rec = dict(metric="images classified/sec (node), CIFAR-10 10-class x 50-step ELBO scoring"
                if args.workload == "cifar10-unet-10x50" else f"images classified/sec (node), {args.workload}",
                value=round(value, 3), unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+               scaling="strong" if args.global_batch else "weak", vs_baseline=None,
                dtype=args.dtype, data="synthetic",
                config=dict(workload=args.workload, images_per_step=B, classes=classes, trials=T,
                            forwards_per_image=classes * T, share_trunk=not args.no_share_trunk,
+                           stages=args.stages, input="haar_dwt2(x0)/2 (HIP kernel)" if dwt else "uniform [-1,1]",
+                           h2d="x resident in HBM before the timed region (not in value)",
                            parallelism=f"grid-shard x{world}" if world > 1 else "single"),
                roofline=roofline, kernels=kernels)
     if flop_fwd:
         rec["ref_equiv_tflops"] = round(value * classes * T * flop_fwd / 1e12, 1)     # reference-equivalent FLOPs
 
-    # ---- CPU baseline: the oracle's reference-structured loop on the host cores (N=1 only) ----
-    if world == 1 and not args.no_cpu_baseline:
+    # ---- CPU oracle legs (N=1 only, after the timed region): parity sub-grid, then the timed CPU baseline ----
+    if world == 1 and not (args.no_cpu_baseline and args.no_parity):
         import oracle
-        ob = (oracle.OracleUNetCondition2D(**kw) if enc == "nn" else oracle.OracleDiT(**kw))
-        ob.load_state_dict(dc.model.state_dict())
-        ocfg = dict(cfg, evaluation_per_stage=[T])
-        oc = oracle.OracleDiffusionClassifier(ob, oracle.AttrBag(**ocfg))
-        if oc.encoder is not None:
-            oc.encoder.load_state_dict(dc.encoder.state_dict())
         cores = usable_cores()
         torch.set_num_threads(cores)
+        lowp_kw = dict(lowp=True) if enc == "nn" else dict(lowp=True, lowp_dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16)
+
+        def make_oracle(lowp, T_):
+            okw = dict(kw, **(lowp_kw if lowp else {}))
+            ob = (oracle.OracleUNetCondition2D(**okw) if enc == "nn" else oracle.OracleDiT(**okw))
+            if lowp and enc == "nn" and args.dtype == "f16":
+                ob._q = lambda t_: t_.to(torch.float16).float()
+            ob.load_state_dict(dc.model.state_dict())
+            oc_ = oracle.OracleDiffusionClassifier(ob, oracle.AttrBag(**dict(cfg, n_stages=1, evaluation_per_stage=[T_], n_keep_per_stage=[1])))
+            if oc_.encoder is not None:
+                oc_.encoder.load_state_dict(dc.encoder.state_dict())
+            return oc_
+
+    if world == 1 and not args.no_parity:
+        # SURVEY §8d "parity gates reported with every number": the same weights and inputs, a sub-grid of the workload
+        # (pb images x pt trials x ALL classes, draws injected), HIP f32 vs the fp32 oracle (bar 1e-4) and the HIP
+        # compute dtype vs the oracle with the kernels' storage rounding / under torch autocast / in fp32.
+        pb_, pt_ = (2, 2) if flop_fwd is None or flop_fwd < 50e9 else (1, 1)
+        print(f"[bench] parity sub-grid: {pb_} images x {pt_} trials x {classes} classes ...", file=sys.stderr, flush=True)
+        gp = torch.Generator().manual_seed(4321)
+        xp = x[:pb_].cpu()
+        tp_ = torch.rand(pt_, pb_, generator=gp)
+        ep_ = torch.randn(pt_, pb_, *xp.shape[1:], generator=gp)
+        saved = (dc.config.compute_dtype, dc.config.evaluation_per_stage, dc.config.n_stages, dc.config.n_keep_per_stage)
+        dc.config.evaluation_per_stage, dc.config.n_stages, dc.config.n_keep_per_stage = [pt_], 1, [1]
+        rel = lambda a, b: float(((a.float() - b.float()).abs() / b.float()).max())
+        par = dict(subgrid=f"{pb_} images x {pt_} trials x {classes} classes, injected (t, eps)")
+        o32 = make_oracle(False, pt_)
+        l32, e32 = o32.classify(xp, t=tp_, eps=ep_, return_errors=True)
+        dc.config.compute_dtype = "f32"
+        lg, eg = dc.classify(xp.to(dev), t=tp_, eps=ep_.to(dev), return_errors=True)
+        par.update(f32_max_rel_eps_mse=rel(eg, e32), f32_bar=1e-4, f32_labels_equal=bool((lg.cpu() == l32).all()))
+        if args.dtype != "f32":
+            dc.config.compute_dtype = args.dtype
+            lg, eg = dc.classify(xp.to(dev), t=tp_, eps=ep_.to(dev), return_errors=True)
+            olp = make_oracle(True, pt_)
+            llp, elp = olp.classify(xp, t=tp_, eps=ep_, return_errors=True)
+            par[f"{args.dtype}_max_rel_vs_storage_rounded_oracle"] = rel(eg, elp)
+            par[f"{args.dtype}_max_rel_vs_fp32_oracle"] = rel(eg, e32)
+            if args.dtype == "bf16" and enc == "nn":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    lac, eac = o32.classify(xp, t=tp_, eps=ep_, return_errors=True)
+                par["bf16_max_rel_vs_autocast_oracle"] = rel(eg, eac)
+                par["autocast_oracle_max_rel_vs_fp32_oracle"] = rel(eac, e32)
+            par[f"{args.dtype}_label_agreement_with_fp32_oracle"] = float((lg.cpu() == l32).float().mean())
+            del olp
+        dc.config.compute_dtype, dc.config.evaluation_per_stage, dc.config.n_stages, dc.config.n_keep_per_stage = saved
+        dc._score_plans.clear()
+        rec["parity"] = {k: (round(v, 7) if isinstance(v, float) else v) for k, v in par.items()}
+        del o32
+
+    # ---- CPU baseline: the oracle's reference-structured loop on the host cores (N=1 only) ----
+    if world == 1 and not args.no_cpu_baseline:
+        oc = make_oracle(False, T)
         print(f"[bench] cpu baseline on {cores} host threads ...", file=sys.stderr, flush=True)
         bs_c = 2 if size <= 32 else 1
         xc = x[:bs_c].cpu()

@@ -263,11 +263,86 @@ __global__ __launch_bounds__(256) void haar_idwt2_kernel(const float* in, float*
   }
 }
 
+typedef float hv4 __attribute__((ext_vector_type(4)));     // native vector: what the nontemporal builtins take
+__device__ __forceinline__ hv4 hv4_make(float a, float b, float c, float d) { hv4 v = {a, b, c, d}; return v; }
+// Wide forms (W a multiple of 8, 16-byte aligned tensors): a lane owns 4 adjacent output pixels of one subband row — two
+// 16-byte loads from each of the two source rows (a wave reads 2 x 2 KiB contiguous), one 16-byte store per subband
+// (a wave writes 4 x 1 KiB contiguous).  Pure streaming: 8 bytes moved per input value, HBM-bound.
+__global__ __launch_bounds__(256) void haar_dwt2_v4_kernel(const float* __restrict__ in, float* __restrict__ out, long long total4,
+                                                           int C, int H, int W, float scale) {
+  const int h = H / 2, w4 = W / 8;
+  const long long hw = (long long)h * (W / 2);
+  const float k = 0.5f * scale;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int xq = (int)(i % w4); long long r = i / w4;
+    const int y = (int)(r % h); r /= h;                         // r = n * C + c
+    const float* src = in + (r * H + 2 * y) * (long long)W + 8 * xq;
+    const hv4 a0 = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src));
+    const hv4 a1 = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src) + 1);
+    const hv4 b0 = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src + W));
+    const hv4 b1 = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src + W) + 1);
+    const float A[4] = {a0.x, a0.z, a1.x, a1.z}, B[4] = {a0.y, a0.w, a1.y, a1.w};
+    const float Cc[4] = {b0.x, b0.z, b1.x, b1.z}, D[4] = {b0.y, b0.w, b1.y, b1.w};
+    float o[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[0][j] = (A[j] + B[j] + Cc[j] + D[j]) * k;
+      o[1][j] = (A[j] + B[j] - Cc[j] - D[j]) * k;
+      o[2][j] = (A[j] - B[j] + Cc[j] - D[j]) * k;
+      o[3][j] = (A[j] - B[j] - Cc[j] + D[j]) * k;
+    }
+    const long long c = r % C, n = r / C;
+    float* dst = out + ((n * 4 * C + 4 * c) * h + y) * (long long)(W / 2) + 4 * xq;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb)
+      __builtin_nontemporal_store(hv4_make(o[sb][0], o[sb][1], o[sb][2], o[sb][3]), reinterpret_cast<hv4*>(dst + sb * hw));
+  }
+}
+__global__ __launch_bounds__(256) void haar_idwt2_v4_kernel(const float* __restrict__ in, float* __restrict__ out, long long total4,
+                                                            int C, int h, int w, float scale) {
+  const int w4 = w / 4;
+  const long long hw = (long long)h * w;
+  const float k = 0.5f * scale;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int xq = (int)(i % w4); long long r = i / w4;
+    const int y = (int)(r % h); r /= h;
+    const long long c = r % C, n = r / C;
+    const float* src = in + ((n * 4 * C + 4 * c) * h + y) * (long long)w + 4 * xq;
+    const hv4 cA = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src));
+    const hv4 cH = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src + hw));
+    const hv4 cV = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src + 2 * hw));
+    const hv4 cD = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(src + 3 * hw));
+    const float a[4] = {cA.x, cA.y, cA.z, cA.w}, hh[4] = {cH.x, cH.y, cH.z, cH.w};
+    const float v[4] = {cV.x, cV.y, cV.z, cV.w}, d[4] = {cD.x, cD.y, cD.z, cD.w};
+    float t[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[2 * j] = (a[j] + hh[j] + v[j] + d[j]) * k;  t[2 * j + 1] = (a[j] + hh[j] - v[j] - d[j]) * k;
+      b[2 * j] = (a[j] - hh[j] + v[j] - d[j]) * k;  b[2 * j + 1] = (a[j] - hh[j] - v[j] + d[j]) * k;
+    }
+    float* dst = out + (r * 2 * h + 2 * y) * (long long)(2 * w) + 8 * xq;
+    __builtin_nontemporal_store(hv4_make(t[0], t[1], t[2], t[3]), reinterpret_cast<hv4*>(dst));
+    __builtin_nontemporal_store(hv4_make(t[4], t[5], t[6], t[7]), reinterpret_cast<hv4*>(dst) + 1);
+    __builtin_nontemporal_store(hv4_make(b[0], b[1], b[2], b[3]), reinterpret_cast<hv4*>(dst + 2 * w));
+    __builtin_nontemporal_store(hv4_make(b[4], b[5], b[6], b[7]), reinterpret_cast<hv4*>(dst + 2 * w) + 1);
+  }
+}
+
+static unsigned haar_grid(long long items) {
+  const long long b = (items + 255) / 256;
+  return (unsigned)(b > 65536 ? 65536 : b);
+}
+
 extern "C" int dc_haar_dwt2(const float* in, float* out, int32_t n, int32_t C, int32_t H, int32_t W, float scale, dc_stream stream) {
   DC_REQUIRE(in && out && n > 0 && C > 0 && H > 0 && W > 0, DC_ERR_ARG, "dc_haar_dwt2: bad args");
   DC_REQUIRE(H % 2 == 0 && W % 2 == 0, DC_ERR_SHAPE, "dc_haar_dwt2: H=%d W=%d must be even", H, W);
   DC_REQUIRE(((uintptr_t)in & 7) == 0, DC_ERR_ALIGN, "dc_haar_dwt2: input must be 8-byte aligned");
   const long long total = (long long)n * C * (H / 2) * (W / 2);
+  if (W % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(haar_dwt2_v4_kernel, dim3(haar_grid(total / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out,
+                       total / 4, C, H, W, scale);
+    return dc_check_launch("dc_haar_dwt2");
+  }
   const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   hipLaunchKernelGGL(haar_dwt2_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, total, C, H, W, scale);
   return dc_check_launch("dc_haar_dwt2");
@@ -276,6 +351,11 @@ extern "C" int dc_haar_idwt2(const float* in, float* out, int32_t n, int32_t C, 
   DC_REQUIRE(in && out && n > 0 && C > 0 && h > 0 && w > 0, DC_ERR_ARG, "dc_haar_idwt2: bad args");
   DC_REQUIRE(((uintptr_t)out & 7) == 0, DC_ERR_ALIGN, "dc_haar_idwt2: output must be 8-byte aligned");
   const long long total = (long long)n * C * h * w;
+  if (w % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(haar_idwt2_v4_kernel, dim3(haar_grid(total / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out,
+                       total / 4, C, h, w, scale);
+    return dc_check_launch("dc_haar_idwt2");
+  }
   const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   hipLaunchKernelGGL(haar_idwt2_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, total, C, h, w, scale);
   return dc_check_launch("dc_haar_idwt2");

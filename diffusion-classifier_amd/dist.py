@@ -31,6 +31,8 @@ def assert_replicated(x, group=None):
     fp = torch.cat([torch.tensor([float(x.shape[0]), float(xf.numel())], dtype=torch.float64, device=xf.device),
                     xf.sum().reshape(1), (xf * xf).sum().reshape(1), xf[::step][:61]])
     ws = dist.get_world_size(group)
+    if fp.is_cuda and dist.get_backend(group) == "gloo":
+        fp = fp.cpu()                    # gloo has no device all-gather
     allfp = torch.empty((ws * fp.numel(),), dtype=fp.dtype, device=fp.device)
     dist.all_gather_into_tensor(allfp, fp.contiguous(), group=group)
     allfp = allfp.view(ws, -1)
@@ -71,8 +73,10 @@ def gather_stage_errors(errors, stage_start, stage_end, rank, world_size, group=
     slab = torch.full((n, ncls), float("inf"), dtype=errors.dtype, device=dev)
     if g_mine.numel():
         slab[: g_mine.numel()] = errors[g_mine % BS, :, stage_start + g_mine // BS]
-    flat = torch.empty((world_size * n, ncls), dtype=errors.dtype, device=dev)   # dim-0 concatenation (gloo needs this form)
-    dist.all_gather_into_tensor(flat, slab.contiguous(), group=group)
+    host = errors.is_cuda and dist.get_backend(group) == "gloo"     # gloo (single-GPU rehearsals, CPU tests) gathers on the host
+    flat = torch.empty((world_size * n, ncls), dtype=errors.dtype, device="cpu" if host else dev)   # dim-0 concatenation (gloo needs this form)
+    dist.all_gather_into_tensor(flat, slab.cpu() if host else slab.contiguous(), group=group)
+    flat = flat.to(dev)
     g = torch.arange(P, device=dev)
     errors[g % BS, :, stage_start + g // BS] = flat[(g % world_size) * n + g // world_size]
     return errors

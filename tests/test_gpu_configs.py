@@ -1,0 +1,251 @@
+"""GPU: parity of the BASELINE.json configurations as `bench.py` runs them.
+
+* config 2 (CIFAR-10 UNet, experiments/cifar10/inference.py:94-116): `classify` with the bench's plan shape — 10 real
+  classes, class-shared trunk AND class-shared skip halves, philox-free injected draws — in f32 against the oracle
+  (north-star bar: per-cell eps-MSE within 1e-4, identical labels) and in bf16 against (a) the oracle with the kernels'
+  storage rounding, (b) the oracle under torch autocast (the reference's own bf16 semantics), (c) the plain
+  fp32 oracle, each with its tolerance stated.
+* config 4 (IPMSA UNet, models/ipmsa-5-unet.py:4-30, layers_per_block=(2,2,2,2,4,2)): one bf16 forward.
+* config 5 (DiT-B/4, models/chexpert-256-dit-b4.py:4-21): all 12 layers in f16, forward and a 2-class classify.
+* config 3 inputs: x = haar_dwt2(x0)/2 exactly as dataset/chexpert.py:146-147 prepares them.
+"""
+import os
+
+import pytest
+import torch
+
+import diffusion_classifier_amd as dca
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+def _randomise_vectors(m):
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+
+
+def _cfg2_pair(seed, cfg):
+    kw = dca.cifar10_unet_kwargs()
+    torch.manual_seed(seed)
+    m = dca.UNetCondition2D(**kw)
+    _randomise_vectors(m)
+    dc = dca.DiffusionClassifier(m, dca.Config(**cfg))
+    with torch.no_grad():
+        dc.encoder.weight.mul_(3.0)            # class tokens far enough apart that classes differ visibly
+    return kw, dc
+
+
+def _oracle_for(kw, dc, cfg, lowp):
+    o = oracle.OracleUNetCondition2D(**kw, lowp=lowp)
+    o.load_state_dict(dc.model.state_dict())
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    oc.encoder.load_state_dict(dc.encoder.state_dict())
+    return oc
+
+
+CFG2 = dict(pred_param="eps", schedule="cosine", noise_d=32, image_size=32, cfg_w=0.0, ema_beta=0.999, ema_warmup=0,
+            ema_update_freq=1, encoder_type="nn", classes=10, n_stages=1, evaluation_per_stage=[3], n_keep_per_stage=[1],
+            n_fast_classes=2)
+
+
+def _draws(BS, T, seed):
+    torch.manual_seed(seed)
+    x = torch.rand(BS, 3, 32, 32) * 2 - 1
+    return x, torch.rand(T, BS), torch.randn(T, BS, 3, 32, 32)
+
+
+def test_cfg2_classify_f32_bench_plan_matches_oracle(monkeypatch):
+    """The plan shape the bench times (k = 10 classes on the 128/128/256/512 architecture: trunk shared per pair, skip
+    halves of up_blocks.2/.3 shared per pair) against the oracle, then the same scores with each sharing switched off."""
+    cfg = dict(CFG2, compute_dtype="f32")
+    kw, dc = _cfg2_pair(41, cfg)
+    oc = _oracle_for(kw, dc, cfg, lowp=False)
+    BS, T = 2, 3
+    x, t, eps = _draws(BS, T, 42)
+    ref_l, ref_e = oc.classify(x, t=t, eps=eps, return_errors=True)
+    dc = dc.to(DEV)
+    got_l, got_e = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    rel = ((got_e - ref_e).abs() / ref_e).max().item()
+    assert rel < 1e-4, rel                                                 # north-star bar
+    assert got_l.cpu().tolist() == ref_l.tolist()
+    plan = next(iter(dc._score_plans.values()))["plan"]
+    names = [mt["name"] for mt in plan.pb.meta]
+    assert plan.n_cls == 10 and sum(n.endswith(".conv1s") for n in names) == 5      # the class-shared skip halves are in play
+    assert plan.pb.n["unit"] == 10 * plan.pb.n["bj"]
+    # the same grid without the class-shared trunk / without the split skip halves: same scores (summation order only)
+    dc.ema.ema_model.share_trunk = False
+    e_noshare = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)[1]
+    dc.ema.ema_model.share_trunk = True
+    monkeypatch.setenv("DCAMD_NO_SKIP_SPLIT", "1")
+    dc._score_plans.clear()
+    e_nosplit = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)[1]
+    for other in (e_noshare, e_nosplit):
+        assert ((other - got_e).abs() / got_e).max().item() < 2e-5
+        assert ((other - ref_e).abs() / ref_e).max().item() < 1e-4
+
+
+def test_cfg2_classify_bf16_bench_plan_three_anchors():
+    """bf16 as the bench runs it (10 classes, shared trunk + skip halves, qstats, up4, folded shortcuts / LayerNorm):
+    per-cell eps-MSE against three CPU anchors, each bound stated; labels must agree wherever the fp32 oracle's
+    best and second-best class means are further apart than the bf16 error bound."""
+    cfg = dict(CFG2, compute_dtype="bf16")
+    kw, dc = _cfg2_pair(43, cfg)
+    oc_lowp = _oracle_for(kw, dc, cfg, lowp=True)
+    oc_f32 = _oracle_for(kw, dc, cfg, lowp=False)
+    BS, T = 2, 3
+    x, t, eps = _draws(BS, T, 44)
+    lp_l, lp_e = oc_lowp.classify(x, t=t, eps=eps, return_errors=True)
+    f32_l, f32_e = oc_f32.classify(x, t=t, eps=eps, return_errors=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):                      # the reference's own bf16 semantics
+        ac_l, ac_e = oc_f32.classify(x, t=t, eps=eps, return_errors=True)
+    got_l, got_e = dc.to(DEV).classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    assert torch.isfinite(got_e).all()
+    rel = lambda a, b: ((a.float() - b.float()).abs() / b.float()).max().item()
+    r_lowp, r_ac, r_f32 = rel(got_e, lp_e), rel(got_e, ac_e), rel(got_e, f32_e)
+    print(f"cfg2 bf16 per-cell eps-MSE max rel err: vs storage-rounded oracle {r_lowp:.2e}, vs autocast oracle {r_ac:.2e}, "
+          f"vs fp32 oracle {r_f32:.2e}; autocast-vs-fp32 itself {rel(ac_e, f32_e):.2e}")
+    assert r_lowp < 1.5e-2, r_lowp         # same rounding points, different fp32 summation order
+    assert r_ac < 2.5e-2, r_ac             # independent bf16 rounding points on both sides
+    assert r_f32 < 2.0e-2, r_f32           # bf16 path as an approximation of the fp32 network
+    assert r_f32 < 2.5 * rel(ac_e, f32_e) + 5e-3     # ...no worse than autocast's own distance from fp32
+    means = f32_e.mean(2)
+    srt = means.sort(1).values
+    decided = (srt[:, 1] - srt[:, 0]) / srt[:, 0] > 2 * r_f32
+    assert (got_l.cpu()[decided] == f32_l[decided]).all()
+
+
+def test_reloading_weights_invalidates_cached_score_plans():
+    """classify -> load_state_dict -> classify must score with the NEW weights."""
+    cfg = dict(CFG2, classes=3, compute_dtype="f32", evaluation_per_stage=[2])
+    kw = dca.small_unet_kwargs()
+    torch.manual_seed(51)
+    m = dca.UNetCondition2D(**kw)
+    dc = dca.DiffusionClassifier(m, dca.Config(**cfg)).to(DEV)
+    BS, T = 2, 2
+    x, t, eps = _draws(BS, T, 52)
+    e_old = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)[1]
+    torch.manual_seed(53)
+    m2 = dca.UNetCondition2D(**kw)
+    _randomise_vectors(m2)
+    dc.ema.ema_model.load_state_dict(m2.state_dict())                      # what load_checkpoint does
+    e_new = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)[1]
+    o = oracle.OracleUNetCondition2D(**kw)
+    o.load_state_dict(m2.state_dict())
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    oc.encoder.load_state_dict(dc.encoder.state_dict())
+    ref = oc.classify(x, t=t, eps=eps, return_errors=True)[1]
+    assert ((e_new - ref).abs() / ref).max().item() < 1e-4
+    assert ((e_old - ref).abs() / ref).max().item() > 1e-3                 # the old weights really were different
+    assert len(dc._score_plans) == 1                                       # the stale plan (and its arena) was dropped
+    # a different trial count on the same classifier gets its own errors buffer
+    dc.config.evaluation_per_stage = [3]
+    x3, t3, eps3 = _draws(BS, 3, 54)
+    e3 = dc.classify(x3.to(DEV), t=t3, eps=eps3.to(DEV), return_errors=True)[1]
+    assert e3.shape == (BS, 3, 3) and torch.isfinite(e3).all()
+
+
+def test_cfg4_ipmsa_unet_forward_bf16():
+    """BASELINE config-4 architecture (models/ipmsa-5-unet.py:4-30): 10x256x256, six levels, layers_per_block
+    (2,2,2,2,4,2), cross-attention at the two deepest levels — one bf16 forward against the storage-rounded oracle
+    and against the fp32 oracle."""
+    kw = dca.ipmsa5_unet_kwargs()
+    torch.manual_seed(61)
+    m = dca.UNetCondition2D(**kw)
+    _randomise_vectors(m)
+    o = oracle.OracleUNetCondition2D(**kw, lowp=True)
+    o.load_state_dict(m.state_dict())
+    torch.manual_seed(62)
+    N = 1
+    x, lam, emb = torch.randn(N, 10, 256, 256) * 0.5, torch.tensor([1.0]), torch.randn(N, 1, 512)
+    with torch.no_grad():
+        ref = o(x, lam, encoder_hidden_states=emb)
+        o.lowp = False
+        ref32 = o(x, lam, encoder_hidden_states=emb)
+    got = m.to(DEV).set_compute_dtype("bf16")(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    assert torch.isfinite(got).all()
+    r, r32 = relerr(got, ref), relerr(got, ref32)
+    print(f"cfg4 bf16 forward rel-L2: vs storage-rounded oracle {r:.2e}, vs fp32 oracle {r32:.2e}")
+    assert r < 2e-2, r
+    assert r32 < 4e-2, r32
+    plan = next(iter(m._plans.values()))
+    names = [mt["name"] for mt in plan.pb.meta]
+    assert "down_blocks.4.resnets.3.conv1" in names                    # down_blocks.4 has four ResNets (tuple layers_per_block)
+    assert any(n.startswith("up_blocks.1.resnets.4") for n in names)   # and its mirror has five
+
+
+def _dit_b4(seed, nclass_rows=10):
+    kw = dict(dca.chexpert_dit_b4_kwargs(True), num_embeds_ada_norm=nclass_rows)
+    torch.manual_seed(seed)
+    m = dca.DiT(**kw)
+    _randomise_vectors(m)
+    o = oracle.OracleDiT(**kw, lowp=True, lowp_dtype=torch.float16)
+    o.load_state_dict(m.state_dict())
+    return kw, m, o
+
+
+def test_cfg5_dit_b4_full_depth_f16_forward_and_classify():
+    """BASELINE config 5 (models/chexpert-256-dit-b4.py:4-21: 12 layers, 12 heads x 64, patch 4; 12x128x128 DWT input ->
+    1024 tokens) in the fp16 path it names: one forward, then a 2-class x 2-trial classify, against the oracle with
+    fp16 storage rounding."""
+    kw, m, o = _dit_b4(71)
+    assert kw["num_layers"] == 12
+    torch.manual_seed(72)
+    N = 2
+    x, lam, lab = torch.randn(N, 12, 128, 128) * 0.5, torch.tensor([2.0, -3.0]), torch.tensor([1, 0])
+    with torch.no_grad():
+        ref = o(x, lam, lab)
+    md = m.to(DEV).set_compute_dtype("f16")
+    got = md(x.to(DEV), lam.to(DEV), lab.to(DEV)).cpu()
+    r = relerr(got, ref)
+    print(f"cfg5 DiT-B/4 12-layer f16 forward rel-L2 vs fp16-storage oracle: {r:.2e}")
+    assert r < 6e-3, r
+    cfg = dict(CFG2, encoder_type="DiT", classes=2, evaluation_per_stage=[2], image_size=128, noise_d=128, compute_dtype="f16")
+    dc = dca.DiffusionClassifier(m.cpu(), dca.Config(**cfg)).to(DEV)
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    BS, T = 1, 2
+    torch.manual_seed(73)
+    xx = torch.rand(BS, 12, 128, 128) * 2 - 1
+    t, eps = torch.rand(T, BS), torch.randn(T, BS, 12, 128, 128)
+    ref_l, ref_e = oc.classify(xx, t=t, eps=eps, return_errors=True)
+    got_l, got_e = dc.classify(xx.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    rel = ((got_e - ref_e).abs() / ref_e).max().item()
+    print(f"cfg5 DiT-B/4 f16 classify per-cell eps-MSE max rel err: {rel:.2e}")
+    assert rel < 5e-3, rel
+    gap = abs(ref_e.mean(2)[0, 0] - ref_e.mean(2)[0, 1]) / ref_e.mean(2).min()
+    if gap > 2 * rel:
+        assert got_l.cpu().tolist() == ref_l.tolist()
+
+
+def test_cfg3_inputs_are_the_haar_transform_of_the_image():
+    """config 3/5 feed x = wavelet_dec_2(image)/2 (dataset/chexpert.py:146-147): the HIP DWT of a batch followed by one
+    cfg3 classify trial equals the oracle's DWT + classify (bf16, storage-rounded oracle)."""
+    kw = dca.chexpert_dwt_unet_kwargs()
+    torch.manual_seed(81)
+    m = dca.UNetCondition2D(**kw)
+    _randomise_vectors(m)
+    cfg = dict(CFG2, classes=2, evaluation_per_stage=[1], image_size=128, noise_d=128, compute_dtype="bf16")
+    dc = dca.DiffusionClassifier(m, dca.Config(**cfg))
+    o = oracle.OracleUNetCondition2D(**kw, lowp=True)
+    o.load_state_dict(m.state_dict())
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    oc.encoder.load_state_dict(dc.encoder.state_dict())
+    torch.manual_seed(82)
+    x0 = torch.rand(1, 3, 256, 256) * 2 - 1
+    x_ref = torch.stack([torch.from_numpy(oracle.haar_dwt2(im.numpy())) for im in x0]) / 2
+    x_hip = dca.wavelet_dec_2(x0.to(DEV), scale=0.5)
+    assert x_hip.shape == (1, 12, 128, 128)
+    assert (x_hip.cpu() - x_ref).abs().max().item() < 2e-6
+    t, eps = torch.rand(1, 1), torch.randn(1, 1, 12, 128, 128)
+    ref_l, ref_e = oc.classify(x_ref, t=t, eps=eps, return_errors=True)
+    got_l, got_e = dc.to(DEV).classify(x_hip, t=t, eps=eps.to(DEV), return_errors=True)
+    rel = ((got_e - ref_e).abs() / ref_e).max().item()
+    print(f"cfg3 bf16 classify (1 trial x 2 classes) per-cell eps-MSE max rel err: {rel:.2e}")
+    assert rel < 2e-2, rel

@@ -109,3 +109,30 @@ def test_sample_matches_reference_golden():
         torch.manual_seed(int(g[tag + ".seed"]))
         out = dc.sample(torch.from_numpy(g[tag + ".x"]), torch.from_numpy(g[tag + ".labels"]), from_t=float(g[tag + ".from_t"]))
         np.testing.assert_allclose(out.numpy(), g[tag + ".out"], rtol=0, atol=2e-6)
+
+
+# ---- f-1 pinned: a checkpoint directory written by the REFERENCE's own save_checkpoint (tools/capture_checkpoint_fixture.py) ----
+CKPT = os.path.join(os.path.dirname(__file__), "golden", "ckpt_tiny_unet")
+
+
+def ckpt_case():
+    g = dict(np.load(os.path.join(CKPT, "expected.npz")))
+    cfg = {k[4:]: (v.tolist() if v.ndim else v.item()) for k, v in g.items() if k.startswith("cfg.")}
+    arch = {k[5:]: (tuple(v.tolist()) if v.ndim else v.item()) for k, v in g.items() if k.startswith("arch.")}
+    return g, cfg, arch
+
+
+def test_reference_written_checkpoint_is_ingested_and_scores_like_the_reference():
+    import oracle
+    g, cfg, arch = ckpt_case()
+    assert sorted(os.listdir(CKPT)) == ["expected.npz", "experiment_state.pth", "model.safetensors", "model_1.safetensors",
+                                        "model_2.safetensors", "optimizer.bin", "random_states_0.pkl", "scheduler.bin"]
+    torch.manual_seed(0)
+    dc = dca.DiffusionClassifier(oracle.OracleUNetCondition2D(**arch), dca.Config(**cfg))     # foreign (plain nn.Module) backbone
+    assert dc.load_checkpoint(CKPT) == (5, 0.75, None)                  # reference :805 (epoch + 1, best metric, comet key)
+    assert int(dc.ema.step) == 123 and bool(dc.ema.initted)
+    online, ema = dc.model.state_dict(), dc.ema.ema_model.state_dict()
+    assert any(not torch.equal(online[k], ema[k]) for k in online)      # EMA weights are their own tensors in model_1
+    lab, err = dc.classify(torch.from_numpy(g["x"]), t=torch.from_numpy(g["t"]), eps=torch.from_numpy(g["eps"]), return_errors=True)
+    np.testing.assert_array_equal(lab.numpy(), g["labels"])
+    np.testing.assert_allclose(err.numpy(), g["errors"], rtol=1e-6)     # same modules, same ops as the reference's run
