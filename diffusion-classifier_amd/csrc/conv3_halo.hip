@@ -46,6 +46,12 @@ struct HaloGeom {
   int hw, hp, HR, nxl;      // halo width, halo pixels per image patch, halo rows per tile, X loads per lane
   int n_img, H, W;
   float inv_hp, inv_hw;     // 1/hp, 1/hw: the loaders' piece -> (image, row, column) split without integer divisions
+  // mosaic (images smaller than 8x8, one whole image per 16-pixel MFMA fragment): the 2^lni images of a patch are laid out as a
+  // 2^lmc-column grid that SHARES its zero borders — cell pitch (th+1) x (tw+1), one separator row / column between and around
+  // the images — so the patch is ONE halo of (rows*(th+1)+1) x (cols*(tw+1)+1) pixels: 32 images of 4x4 = 21 x 41 = 861 rows
+  // (7 LDS-DMA pieces per lane) instead of 32 separate 6x6 halos (1152 rows, 9 pieces).  A tap is still one row offset.
+  int mos, lmc;
+  float inv_ch, inv_cw;     // 1/(th+1), 1/(tw+1)
 };
 
 constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
@@ -145,6 +151,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     pp[i] = -1;
     if (i < g.nxl && hr < g.HR) {
       // hr < 2^12 and (hr + 0.5) / hp is at least 0.5 / hp away from an integer: the fp32 product floors exactly
+      if (g.mos) {
+        // mosaic: halo position (hy, hx) -> grid cell (cy, cx) and position inside the cell; row / column 0 of a cell is a shared
+        // zero separator (all quotients are < 2^10 and at least half a step away from an integer: the fp32 products floor exactly)
+        const int hy = (int)(((float)hr + 0.5f) * g.inv_hw), hx = hr - hy * g.hw;
+        const int cy = (int)(((float)hy + 0.5f) * g.inv_ch), ry = hy - cy * (th + 1);
+        const int cx = (int)(((float)hx + 0.5f) * g.inv_cw), rx = hx - cx * (tw + 1);
+        if (ry > 0 && rx > 0) pp[i] = (((cy << g.lmc) + cx) << 20) | ((ry - 1) * g.W + rx - 1);
+        continue;
+      }
       const int img = (int)(((float)hr + 0.5f) * g.inv_hp), r = hr - img * g.hp;
       const int hy = (int)(((float)r + 0.5f) * g.inv_hw), hx = r - hy * g.hw;
       const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
@@ -249,7 +264,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   for (int j = 0; j < TM; ++j) {
     const int p = wm * 128 + j * 16;
     const int img = p >> (g.ltw + g.lth), py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
-    joff[j] = __builtin_amdgcn_readfirstlane((img * g.hp + py * g.hw + px) * 64);
+    const int o = g.mos ? ((img >> g.lmc) * (th + 1) + py) * g.hw + (img & ((1 << g.lmc) - 1)) * (tw + 1) + px : img * g.hp + py * g.hw + px;
+    joff[j] = __builtin_amdgcn_readfirstlane(o * 64);
   }
   const int woff0 = lds64_off(wn * 64 + lr, lq);
 
@@ -525,7 +541,9 @@ bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
   // epilogue variant; an activation or a gate goes to igemm_pipe.hip (the UNets apply SiLU in the GroupNorm pass)
   if (a.taps != 9 || a.stride != 1 || a.act != DC_ACT_NONE || a.gate) return false;
   const int H = a.Hin, W = a.Win;
-  if (H < 8 || W < 8 || (H & (H - 1)) || (W & (W - 1))) return false;     // 4x4 and smaller stay on igemm_pipe
+  static const bool no_mosaic = getenv("DCAMD_NO_MOSAIC") != nullptr;
+  const bool mosaic = !no_mosaic && H == 4 && W == 4 && !a.upsample;                      // 4x4 images: 32 per patch, shared zero borders (HaloGeom::mos)
+  if (!mosaic && (H < 8 || W < 8 || (H & (H - 1)) || (W & (W - 1)))) return false;     // anything else below 8x8 stays on igemm_pipe
   if ((long long)a.M >= (1LL << 31)) return false;
   const int bke = 64 / dc_dtype_size(dtype);
   if (a.C0 % bke || a.C1 % bke) return false;
@@ -565,7 +583,18 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
-  g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
+  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f;
+  if (g.H < 8 || g.W < 8) {            // whole small images: mosaic with shared zero borders (only the 512-pixel patch takes them)
+    if (NW != 8 || tw != g.W || th != g.H || ni < 2) { dc_set_error("conv3_halo: %dx%d images need the 8-wave patch", g.H, g.W); return DC_ERR_SHAPE; }
+    g.mos = 1;
+    g.lmc = (g.lni + 1) / 2;           // columns >= rows: 32 images -> 8 x 4
+    const int cols = 1 << g.lmc, rows = ni >> g.lmc;
+    g.hw = cols * (tw + 1) + 1;
+    g.hp = 0;
+    g.HR = (rows * (th + 1) + 1) * g.hw;
+    g.inv_ch = 1.0f / (float)(th + 1); g.inv_cw = 1.0f / (float)(tw + 1);
+  }
+  g.inv_hp = g.hp ? 1.0f / (float)g.hp : 0.f; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + Cfg::NT - 1) / Cfg::NT;
   if (g.HR > Cfg::XROWS || g.nxl > Cfg::NXL || g.nxl < 3) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;

@@ -294,7 +294,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   // four-phase upsample conv (W in the phase-summed form): the caller opted in, so anything else is an error
   if (p->up4) {
     const bool up4_halo = bn == 128 && !use_v1 && !no_halo && !a.src1 && dc_conv3_up4_applicable(a, p->dtype) &&
-                          (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0));
+                          (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0 &&
+                                         (a.Hin >> 1) >= 8 && (a.Win >> 1) >= 8));      // no quad statistics from mosaic (< 8x8) patches
     // sources smaller than 8x8 (4x4 -> 8x8): the same four phases on the tap-gather kernel (no quad statistics there)
     static const bool no_pipe_up4 = getenv("DCAMD_NO_PIPE_UP4") != nullptr;
     const bool up4_pipe = !up4_halo && !no_pipe_up4 && bn == 128 && !use_v1 && !a.src1 && !a.qstats && p->taps == 9 && p->stride == 1 &&
@@ -332,7 +333,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   }
   if (a.qstats) {
     const bool thin_q = !env_v1 && dc_conv3_thin_applicable(a, p->dtype);
-    const bool qs_ok = halo_ok && !thin_q && p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0;
+    const bool qs_ok = halo_ok && !thin_q && p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0 &&
+                       a.Hin >= 8 && a.Win >= 8;          // mosaic patches (images below 8x8) emit none: a wave's half holds four images
     if (!qs_ok) {
       if (variant) { *variant = "qstats-unsupported"; return DC_ERR_UNSUPPORTED; }
       dc_set_error("dc_igemm: qstats given but this problem cannot emit quad statistics (see dc_igemm_qstats_parts)");

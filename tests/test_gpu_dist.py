@@ -36,7 +36,6 @@ def test_hip_runner_world_size_2_is_bit_identical_to_world_size_1(tmp_path):
     one = _launch(1, tmp_path)[0]
     two = _launch(2, tmp_path)
     assert int(one["hip"][0]) == 1
-    assert np.isfinite(one["err_p"]).all()
     pruned = np.isinf(one["err"])
     assert pruned.any() and not pruned.all()                       # two-stage pruning really left cells unevaluated
     for r in two:

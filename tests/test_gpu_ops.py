@@ -111,6 +111,62 @@ def test_conv3x3(dt, case):
     assert maxrel(got, ref) < TOL[dt], (case, maxrel(got, ref))
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("case", ["plain", "concat", "maps", "side", "ragged_patch", "deep"])
+def test_conv3x3_4x4_images_on_mosaic_halo_patches(dt, case):
+    """3x3 convs of 4x4 images (cfg2's deepest level: reference nets/unet.py:186-195 at block_out_channels[-1]) run on the halo
+    kernel as a mosaic — 32 whole images per 512-pixel patch laid out as an 8x4 grid that shares its zero borders — so every
+    input pixel is fetched once per patch instead of once per tap.  Same checks as test_conv3x3."""
+    torch.manual_seed(5)
+    g = E.bke(dt)
+    N, C0, C1, Cout = 40, 2 * g, 0, 128          # 40 images: one full patch of 32 and a ragged one of 8
+    if case == "concat":
+        C1 = 3 * g
+    if case == "ragged_patch":
+        N, Cout = 3, 256
+    if case == "deep":
+        N, C0, C1, Cout = 33, 8 * g, 8 * g, 256   # K = 9 * 1024 (bf16): the up-path ResNets of the 4x4 level
+    H = W = 4
+    q = lambda t: t.to(TD[dt]).float()
+    x0 = q(torch.randn(N, C0, H, W))
+    x1 = q(torch.randn(N, C1, H, W)) if C1 else None
+    w = q(torch.randn(Cout, C0 + C1, 3, 3) / (3 * (C0 + C1) ** 0.5))
+    b = torch.randn(Cout)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    n_out, map0 = N, None
+    if case == "maps":
+        m = torch.randint(0, N, (77,), dtype=torch.int32)
+        n_out, xin, map0 = 77, xin[m.long()], m.to(DEV)
+    ref = F.conv2d(xin, w, b, padding=1)
+    side = None
+    if case == "side":
+        C2 = 4 * g
+        x2 = q(torch.randn(n_out, C2, H, W))
+        w2 = q(torch.randn(Cout, C2) / C2 ** 0.5)
+        ref = ref + torch.einsum("nchw,oc->nohw", x2, w2)
+        side = (nhwc(x2, dt), E.pack_matrix(w2, dt, DEV), C2)
+    rv = torch.randn(n_out, Cout)
+    res = q(torch.randn(n_out, Cout, H, W))
+    ref = ref + rv[:, :, None, None] + res
+    Wp = E.pack_conv3x3(w, dt, DEV)
+    out = torch.full((n_out, H, W, Cout), float("nan"), dtype=TD[dt], device=DEV)
+    a0, a1 = nhwc(x0, dt), (nhwc(x1, dt) if C1 else None)
+    bd, rvd, resd = b.to(DEV), rv.to(DEV).contiguous(), nhwc(res, dt)
+    kw = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n_out, Hin=H, Win=W, Hout=H, Wout=W,
+              src0=ptr(a0), map0=ptr(map0), C0=C0, ld0=0, src1=ptr(a1), map1=ptr(map0) if C1 else None, C1=C1, ld1=0,
+              W=ptr(Wp), Cout=Cout, tile_n=128, bias=ptr(bd), rowvec=ptr(rvd), rowvec_map=None, rowvec_ld=Cout,
+              act=L.ACT_NONE, residual=ptr(resd), res_map=None, res_dtype=dt, res_ld=Cout, out=ptr(out), out_dtype=dt, out_ld=Cout,
+              src2=ptr(side[0]) if side else None, W2=ptr(side[1]) if side else None, C2=side[2] if side else 0, ld2=0)
+    p = L.IgemmParams(**kw)
+    if os.environ.get("DCAMD_NO_MOSAIC") is None:
+        assert L.lib().dc_igemm_variant(p).decode().startswith("conv3_halo<"), L.lib().dc_igemm_variant(p)
+        assert L.lib().dc_igemm_qstats_parts(p) == 0          # no quad statistics from mosaic patches
+    run_igemm(**kw)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert maxrel(got, ref) < TOL[dt], (case, maxrel(got, ref))
+
+
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
 @pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_SILU, L.ACT_GELU_TANH, L.ACT_GEGLU])
 def test_gemm_epilogues(dt, act):
@@ -585,7 +641,7 @@ def test_conv3x3_quad_statistics_feed_groupnorm(dt, shape):
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
 @pytest.mark.parametrize("shape", [(3, 8, 8, 128), (2, 16, 16, 256), (2, 32, 32, 128), (5, 8, 16, 128), (3, 16, 8, 384), (9, 8, 8, 256),
-                                   (21, 4, 4, 256), (3, 4, 4, 128), (5, 2, 2, 128)])      # sources < 8x8: tap-gather kernel
+                                   (21, 4, 4, 256), (3, 4, 4, 128), (70, 4, 4, 128), (5, 2, 2, 128)])   # 4x4: mosaic halo patches; 2x2: tap-gather kernel
 def test_upsample_conv_as_four_phases(dt, shape):
     """dc_igemm up4: nearest-2x upsample + 3x3 conv == four 2x2-tap convs of the low-resolution tensor with phase-summed
     weights (engine.pack_up4).  Checked against F.conv2d(F.interpolate(x)), together with the quad statistics."""
@@ -606,11 +662,12 @@ def test_upsample_conv_as_four_phases(dt, shape):
     kw = dict(dtype=dt, taps=9, stride=1, upsample=1, n_img=n, Hin=2 * H, Win=2 * W, Hout=2 * H, Wout=2 * W, src0=ptr(a0), C0=C0,
               W=ptr(W4), Cout=Cout, tile_n=128, bias=ptr(bd), out=ptr(out), out_dtype=dt, out_ld=Cout, up4=1)
     p = L.IgemmParams(**kw)
-    halo = H >= 8 and W >= 8
+    halo = H >= 8 and W >= 8          # quad statistics come from >= 8x8 halo patches only
+    on_halo = halo or (H == 4 and W == 4 and os.environ.get("DCAMD_NO_MOSAIC") is None)    # 4x4 sources: mosaic patches of 32 images
     assert lib.dc_igemm_up4_ok(p) == 1
-    assert lib.dc_igemm_variant(p).decode().startswith("conv3_up4<" if halo else "igemm_pipe_up4<")
+    assert lib.dc_igemm_variant(p).decode().startswith("conv3_up4<" if on_halo else "igemm_pipe_up4<")
     parts = lib.dc_igemm_qstats_parts(p)
-    assert parts == (4 * max(1, H * W // 128) if halo else 0)     # the tap-gather kernel forms no quad statistics
+    assert parts == (4 * max(1, H * W // 128) if halo else 0)     # the tap-gather kernel and the mosaic form no quad statistics
     qs = torch.full((n, max(parts, 1), Cout // 4, 2), float("nan"), device=DEV)
     run_igemm(**(dict(kw, qstats=ptr(qs)) if halo else kw))
     got = out.float().cpu().permute(0, 3, 1, 2)
