@@ -76,7 +76,10 @@ class Op(C.Structure):
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
            "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_igemm_side_ok", "dc_igemm_ln_ok", "dc_igemm_qstats_parts", "dc_igemm_up4_ok", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
-           "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_run_plan", "dc_run_plan_timed"]
+           "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_stage_topk", "dc_reduce_argmin", "dc_stage_maps", "dc_run_plan", "dc_run_plan_timed",
+           "dc_packed_bytes", "dc_pack_weights_matrix", "dc_pack_weights_conv3x3", "dc_pack_weights_up4", "dc_pack_weights_geglu",
+           "dc_fold_layernorm_bias", "dc_workspace_bytes_groupnorm", "dc_workspace_bytes_igemm", "dc_workspace_bytes_attention",
+           "dc_workspace_bytes_layernorm"]
 
 _lib = None
 
@@ -109,7 +112,15 @@ def lib():
                        ("dc_run_plan_timed", [C.POINTER(Op), i32, vp, vp]),
                        ("dc_philox_normal", [vp, i64, i64, vp, u64, vp]),
                        ("dc_haar_dwt2", [vp, vp, i32, i32, i32, i32, f32, vp]),
-                       ("dc_haar_idwt2", [vp, vp, i32, i32, i32, i32, f32, vp])]:
+                       ("dc_haar_idwt2", [vp, vp, i32, i32, i32, i32, f32, vp]),
+                       ("dc_pack_weights_matrix", [vp, i32, i32, i32, vp, vp, vp, i32, i32, vp]),
+                       ("dc_pack_weights_conv3x3", [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+                       ("dc_pack_weights_up4", [vp, i32, i32, vp, i32, i32, vp]),
+                       ("dc_pack_weights_geglu", [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+                       ("dc_fold_layernorm_bias", [vp, vp, vp, i32, i32, vp, vp]),
+                       ("dc_stage_topk", [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+                       ("dc_reduce_argmin", [vp, i32, i32, i32, i32, vp, vp, vp]),
+                       ("dc_stage_maps", [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp])]:
         fn = getattr(L, name)
         fn.argtypes = argt
         fn.restype = i32
@@ -127,6 +138,12 @@ def lib():
     L.dc_igemm_gn_fusable.restype = i32
     L.dc_igemm_cout_pad.argtypes = [i32, i32]
     L.dc_igemm_cout_pad.restype = i32
+    L.dc_packed_bytes.argtypes = [i32, i32, i32, i32]
+    L.dc_packed_bytes.restype = i64
+    for name, pt in (("dc_workspace_bytes_groupnorm", GroupnormParams), ("dc_workspace_bytes_igemm", IgemmParams),
+                     ("dc_workspace_bytes_attention", AttentionParams), ("dc_workspace_bytes_layernorm", LayernormParams)):
+        getattr(L, name).argtypes = [C.POINTER(pt)]
+        getattr(L, name).restype = i64
     L.dc_groupnorm_ws_floats.argtypes = [i32, i32, i32]
     L.dc_groupnorm_ws_floats.restype = i64
     L.dc_groupnorm_splits.argtypes = [i32, i32, i32]

@@ -52,7 +52,15 @@ struct HaloGeom {
   // (7 LDS-DMA pieces per lane) instead of 32 separate 6x6 halos (1152 rows, 9 pieces).  A tap is still one row offset.
   int mos, lmc;
   float inv_ch, inv_cw;     // 1/(th+1), 1/(tw+1)
+  // start stagger (speed only, never correctness): the workgroups of the first resident generation that share a CU start
+  // together and, doing equal work, stay in phase — prologue beside prologue, epilogue beside epilogue, for the whole launch.
+  // Delaying one of each pair by part of a tile's duration puts one workgroup's HBM-bound prologue / epilogue beside the
+  // other's MFMA loop.  mode 0: off; 1: second arrival on a CU (per-CU arrival counter keyed by the hardware CU id);
+  // 2: blocks [256, 512); 3: odd blocks below 512; 4: pseudo-random delay below stagger_cyc for blocks below 512.
+  int stagger_mode, stagger_cyc;
 };
+
+static __device__ unsigned g_cu_arrivals[4096];     // per hardware CU: workgroups of this library seen so far (parity = stagger role)
 
 constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
 
@@ -114,6 +122,27 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (g.stagger_mode && blockIdx.x < 512) {
+    int cyc = 0;
+    if (g.stagger_mode == 1) {
+      int* flag = reinterpret_cast<int*>(smem);
+      if (t == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));     // HW_ID[15:8]: cu_id, sh_id, se_id
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID[3:0]
+        *flag = (int)(atomicAdd(&g_cu_arrivals[((xcc & 15) << 8) | (hw & 255)], 1u) & 1u);
+      }
+      __syncthreads();
+      cyc = *flag ? g.stagger_cyc : 0;
+      __syncthreads();
+    } else if (g.stagger_mode == 2) cyc = blockIdx.x >= 256 ? g.stagger_cyc : 0;
+    else if (g.stagger_mode == 3) cyc = (blockIdx.x & 1) ? g.stagger_cyc : 0;
+    else cyc = (int)((blockIdx.x * 2654435761u >> 8) % (unsigned)(g.stagger_cyc > 0 ? g.stagger_cyc : 1));
+    cyc = __builtin_amdgcn_readfirstlane(cyc);
+    if (cyc > 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)cyc) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   const int wm = wave >> 1, wn = wave & 1;      // NW/2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
@@ -595,6 +624,13 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
     g.inv_ch = 1.0f / (float)(th + 1); g.inv_cw = 1.0f / (float)(tw + 1);
   }
   g.inv_hp = g.hp ? 1.0f / (float)g.hp : 0.f; g.inv_hw = 1.0f / (float)g.hw;
+  static const int st_mode = getenv("DCAMD_HALO_STAGGER") ? atoi(getenv("DCAMD_HALO_STAGGER")) : 0;
+  static const int st_pct = getenv("DCAMD_HALO_STAGGER_PCT") ? atoi(getenv("DCAMD_HALO_STAGGER_PCT")) : 50;
+  // estimated lifetime of a tile in cycles (~1300 per tap step of a co-resident pair + ~20 k of prologue / epilogue); the delay is
+  // st_pct % of it.  Only when the grid has more than one resident generation and two workgroups share a CU (NW = 4).
+  const long long steps = (long long)((a.C0 + a.C1) / (64 / (int)sizeof(T))) * (up4 ? 4 : 9) + (a.src2 ? a.C2 / (64 / (int)sizeof(T)) : 0);
+  g.stagger_mode = NW == 4 ? st_mode : 0;
+  g.stagger_cyc = (int)((steps * 1300 + 20000) * st_pct / 100);
   g.nxl = (g.HR * 4 + Cfg::NT - 1) / Cfg::NT;
   if (g.HR > Cfg::XROWS || g.nxl > Cfg::NXL || g.nxl < 3) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
@@ -663,6 +699,7 @@ static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
+  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.stagger_mode = 0; g.stagger_cyc = 0;
   g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + ThinCfg::NT - 1) / ThinCfg::NT;
   if (g.nxl > ThinCfg::NXL) { dc_set_error("conv3_thin: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }

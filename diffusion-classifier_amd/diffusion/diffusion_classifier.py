@@ -173,18 +173,16 @@ class DiffusionClassifier(nn.Module):
             runner = _ForeignRunner(self, backbone, x, T, draws)       # user-supplied nn.Module, eager torch
         for i in range(cfg.n_stages):
             pairs = D.local_pairs(ends[i], ends[i + 1], BS, rank, ws)
-            runner.run_stage(pairs, classes)
+            runner.run_stage(pairs, classes, stage=(ends[i], rank, ws))
             errors = runner.errors()
             D.gather_stage_errors(errors, ends[i], ends[i + 1], rank, ws, group=group)
-            errors_cpu = errors.cpu()
-            # stage end: identical torch ops to the reference (:718-721), on every rank
-            num_keep = cfg.n_keep_per_stage[i]
-            end_of_stage_errors = errors_cpu[:, :, :ends[i + 1]].mean(dim=2)
-            _, keep_indices = torch.topk(end_of_stage_errors, num_keep, dim=1, largest=False)
-            classes = keep_indices
+            # stage end (:718-721), identically on every rank: mean over the trials so far, the k smallest classes per image.
+            # HIP backbones: on the device (dc_stage_topk / dc_reduce_argmin; the next stage's work-unit maps are built
+            # there too), so a multi-stage / fast classify never copies errors to the host between stages.
+            classes = runner.stage_end(errors, ends[i + 1], cfg.n_keep_per_stage[i], last=i == cfg.n_stages - 1)
         assert classes.shape[1] == 1, "Only one class should be selected at the end of the classification process."
-        out = classes[:, 0].to(x.device)
-        return (out, errors_cpu) if return_errors else out
+        out = classes[:, 0].to(device=x.device, dtype=torch.int64)
+        return (out, errors.cpu()) if return_errors else out
 
     # ---- callers of the hot path (reference :532-578) ----------------------------------------
     @torch.no_grad()
@@ -362,7 +360,13 @@ class _ForeignRunner:
     def errors(self):
         return self.err
 
-    def run_stage(self, pairs, classes):
+    def stage_end(self, errors, t_end, num_keep, last=False):
+        # identical torch ops to the reference (:718-721)
+        end_of_stage_errors = errors.cpu()[:, :, :t_end].mean(dim=2)
+        _, keep_indices = torch.topk(end_of_stage_errors, num_keep, dim=1, largest=False)
+        return keep_indices
+
+    def run_stage(self, pairs, classes, stage=None):
         dc, x, d = self.dc, self.x, self.d
         by_trial = {}
         for j, b in pairs:
@@ -455,12 +459,27 @@ class _HipRunner:
             self.err_dev = torch.full((BS * ncls * self.T + 1,), float("inf"), dtype=torch.float32, device=self.dev)
         return self.err_dev[:-1].view(BS, ncls, self.T)
 
-    def run_stage(self, pairs, classes):
+    def stage_end(self, errors, t_end, num_keep, last=False):
+        """Mean over trials [0, t_end) and the num_keep smallest classes per image, on the device.  Returns [BS, num_keep]:
+        int64 labels for the last stage (dc_reduce_argmin), else the int32 class lists the next stage's maps are built from."""
+        BS, ncls, T = errors.shape
+        assert errors.is_contiguous() and errors.dtype == torch.float32
+        if last and num_keep == 1:
+            keep = torch.empty((BS, 1), dtype=torch.int64, device=errors.device)
+            L.check(self.lib.dc_reduce_argmin(errors.data_ptr(), BS, ncls, T, t_end, keep.data_ptr(), None, L.stream_ptr()), "dc_reduce_argmin")
+        else:
+            keep = torch.empty((BS, num_keep), dtype=torch.int32, device=errors.device)
+            L.check(self.lib.dc_stage_topk(errors.data_ptr(), BS, ncls, T, t_end, num_keep, keep.data_ptr(), None, L.stream_ptr()), "dc_stage_topk")
+        return keep
+
+    def run_stage(self, pairs, classes, stage=None):
+        """pairs: this rank's (trial, image) pairs of the stage = D.local_pairs(t0, t1, BS, rank, world); stage = (t0, rank, world)."""
         if not pairs:
             return
         dc, d, dev, T = self.dc, self.d, self.dev, self.T
         BS, Cc, H, W = self.x.shape
         ncls, k = dc.config.classes, classes.shape[1]
+        on_dev = classes.is_cuda                         # stages >= 1: the surviving classes never left the device
         n_bj = min(len(pairs), max(1, self._units_per_launch(H, W, k) // k))
         sp = self._plan(n_bj, k)
         plan, score, U = sp["plan"], sp["score"], sp["U"]
@@ -481,7 +500,7 @@ class _HipRunner:
         # the index part of every control block (pair ids, image / class / output maps) depends on (pairs, classes) only:
         # built once and kept (stage 0 of every call sees the same pairs and the full class list); per call only the
         # three float rows (lambda, alpha, sigma of this call's t draws) are gathered.  Host time here is GPU idle time.
-        ck = (n_bj, len(pairs), pairs[0], pairs[-1], T, ncls, classes.numpy().tobytes())
+        ck = (n_bj, len(pairs), pairs[0], pairs[-1], T, ncls, b"dev" if on_dev else classes.numpy().tobytes())
         cache = sp.setdefault("idx_cache", {})
         ent = cache.get(ck)
         if ent is None:
@@ -495,16 +514,17 @@ class _HipRunner:
                 pad = n_bj - len(chunk)
                 js = torch.tensor([p[0] for p in chunk] + [chunk[0][0]] * pad)
                 bs = torch.tensor([p[1] for p in chunk] + [chunk[0][1]] * pad)
-                cl = classes[bs]                                           # [n_bj, k] class id of every unit
-                oi = (bs[:, None] * ncls + cl) * T + js[:, None]           # errors[b, class, j], flat
-                if pad:
-                    oi[len(chunk):] = dump
                 o = 2 * n_bj
                 row[0:o].view(torch.int64).copy_(bs * T + js)
                 o += 3 * n_bj
                 row[o:o + n_bj].copy_(bs.to(torch.int32)); o += n_bj
-                row[o:o + U].copy_(cl.reshape(-1).to(torch.int32)); o += U
-                row[o:o + U].copy_(oi.reshape(-1).to(torch.int32))
+                if not on_dev:
+                    cl = classes[bs]                                       # [n_bj, k] class id of every unit
+                    oi = (bs[:, None] * ncls + cl) * T + js[:, None]       # errors[b, class, j], flat
+                    if pad:
+                        oi[len(chunk):] = dump
+                    row[o:o + U].copy_(cl.reshape(-1).to(torch.int32)); o += U
+                    row[o:o + U].copy_(oi.reshape(-1).to(torch.int32))
                 jsb.append((js, bs))
             ent = cache[ck] = (tmpl, jsb)
         tmpl, jsb = ent
@@ -516,9 +536,20 @@ class _HipRunner:
                 host[m, o:o + n_bj].view(torch.float32).copy_(src[js, bs])
                 o += n_bj
         CHW = Cc * H * W
+        hw = 6 * n_bj                                    # words of a control block the host owns (pair ids, lambda / alpha / sigma, image map)
+        if on_dev:
+            # class-dependent maps of every micro-batch of the stage, built on the device from the surviving classes
+            t0, rank, ws = stage
+            maps = torch.empty((n_mb, 2 * U), dtype=torch.int32, device=dev)
+            L.check(self.lib.dc_stage_maps(classes.data_ptr(), BS, ncls, T, k, t0, len(pairs), rank, ws, n_bj, n_mb, dump,
+                                           maps.data_ptr(), L.stream_ptr()), "dc_stage_maps")
         for m in range(n_mb):
             chunk = pairs[m * n_bj:(m + 1) * n_bj]
-            sp["ctl"].copy_(host[m], non_blocking=True)
+            if on_dev:
+                sp["ctl"][:hw].copy_(host[m, :hw], non_blocking=True)
+                sp["ctl"][hw:].copy_(maps[m], non_blocking=True)
+            else:
+                sp["ctl"].copy_(host[m], non_blocking=True)
             if d["philox"]:
                 L.check(self.lib.dc_philox_normal(score["eps"].data_ptr(), n_bj, CHW, sp["pair_id"].data_ptr(),
                                                   d["seed"], L.stream_ptr()), "dc_philox_normal")

@@ -400,55 +400,80 @@ class PlanBuilder:
 # ======================================================================================
 #                                   weight packing
 # ======================================================================================
-def _pad_rows(w, rows):
-    if w.shape[0] == rows:
-        return w
-    out = torch.zeros((rows,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
-    out[: w.shape[0]] = w
+# The packed layouts belong to the C-ABI (include/dcamd.h, "weight packing"): these wrappers only move the fp32 parameter tensor to
+# the device and call libdcamd's packers — nothing here knows how a packed row is laid out.
+def _dev32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _packed(rows, cols, dt, device, lead=()):
+    return torch.empty(tuple(lead) + (rows, cols), dtype=TORCH_DT[dt], device=device)
+
+
+def pack_matrix(w2d, dt, device, tile_n=128, kpad=None, col_scale=None):
+    """[Cout, K] fp32 (Linear / Conv2d 1x1 weight) -> packed [Cout_pad, kpad or K] in dt (dc_pack_weights_matrix).
+    col_scale [K]: a LayerNorm gamma folded into the columns."""
+    w = _dev32(w2d.reshape(w2d.shape[0], -1), device)
+    cout, K = w.shape
+    kp = K if kpad is None else kpad
+    out = _packed(L.lib().dc_igemm_cout_pad(cout, tile_n), kp, dt, device)
+    cs = None if col_scale is None else _dev32(col_scale, device)
+    L.check(L.lib().dc_pack_weights_matrix(w.data_ptr(), cout, K, kp, None, None if cs is None else cs.data_ptr(), out.data_ptr(), dt, tile_n,
+                                           L.stream_ptr()), "dc_pack_weights_matrix")
     return out
 
 
-def pack_matrix(w2d, dt, device, tile_n=128):
-    """[Cout, K] fp32 -> packed [Cout_pad, K] in dt (rows zero padded to the N tile)."""
-    rows = L.lib().dc_igemm_cout_pad(w2d.shape[0], tile_n)
-    return _pad_rows(w2d.detach().to(device=device, dtype=torch.float32), rows).to(TORCH_DT[dt]).contiguous()
-
-
-def pack_conv3x3(w, dt, device, tile_n=128, kpad=None):
-    """[Cout, Cin, 3, 3] -> [Cout_pad, 9*Cin (padded to kpad)], k = (ky*3+kx)*Cin + c."""
-    co, ci = w.shape[0], w.shape[1]
-    m = w.detach().permute(0, 2, 3, 1).reshape(co, 9 * ci)
-    if kpad is not None and kpad != 9 * ci:
-        mm = torch.zeros(co, kpad, dtype=m.dtype, device=m.device)
-        mm[:, : 9 * ci] = m
-        m = mm
-    return pack_matrix(m, dt, device, tile_n)
+def pack_conv3x3(w, dt, device, tile_n=128, kpad=None, c_lo=0, c_hi=None):
+    """Conv2d weight [Cout, Cin, 3, 3], input channels [c_lo, c_hi) -> packed [Cout_pad, 9*C (padded to kpad)] (dc_pack_weights_conv3x3)."""
+    wd = _dev32(w, device)
+    cout, cin = wd.shape[0], wd.shape[1]
+    c_hi = cin if c_hi is None else c_hi
+    kp = 9 * (c_hi - c_lo) if kpad is None else kpad
+    out = _packed(L.lib().dc_igemm_cout_pad(cout, tile_n), kp, dt, device)
+    L.check(L.lib().dc_pack_weights_conv3x3(wd.data_ptr(), cout, cin, c_lo, c_hi, kp, out.data_ptr(), dt, tile_n, L.stream_ptr()),
+            "dc_pack_weights_conv3x3")
+    return out
 
 
 def pack_up4(w, dt, device, tile_n=128):
-    """[Cout, Cin, 3, 3] -> [4, Cout_pad, 4*Cin]: the four-phase form of "nearest-2x upsample, then 3x3 conv"
-    (dc_igemm_params.up4).  Output pixel (2y+a, 2x+b) reads the 2x2 source pixels (y+a-1+dy, x+b-1+dx); the 3x3 taps that
-    land on the same source pixel are summed in fp32: rows a=0 -> (k0 | k1+k2), a=1 -> (k0+k1 | k2), columns alike.
-    k = (dy*2+dx)*Cin + c."""
-    w = w.detach().to(torch.float32)
-    sets = (((0,), (1, 2)), ((0, 1), (2,)))
-    phases = []
-    for a in range(2):
-        for b in range(2):
-            taps = []
-            for dy in range(2):
-                for dx in range(2):
-                    acc = 0
-                    for ky in sets[a][dy]:
-                        for kx in sets[b][dx]:
-                            acc = acc + w[:, :, ky, kx]
-                    taps.append(acc)                                  # [Cout, Cin]
-            phases.append(pack_matrix(torch.cat(taps, 1), dt, device, tile_n))
-    return torch.stack(phases).contiguous()
+    """Conv2d weight [Cout, Cin, 3, 3] -> [4, Cout_pad, 4*Cin]: the four-phase form of "nearest-2x upsample, then 3x3 conv"
+    (dc_pack_weights_up4 / dc_igemm_params.up4)."""
+    wd = _dev32(w, device)
+    cout, cin = wd.shape[0], wd.shape[1]
+    out = _packed(L.lib().dc_igemm_cout_pad(cout, tile_n), 4 * cin, dt, device, lead=(4,))
+    L.check(L.lib().dc_pack_weights_up4(wd.data_ptr(), cout, cin, out.data_ptr(), dt, tile_n, L.stream_ptr()), "dc_pack_weights_up4")
+    return out
+
+
+def pack_geglu(w, b, dt, device, ln_gamma=None, ln_beta=None):
+    """GEGLU projection [2*n_half, K] + bias -> (packed weight, packed fp32 bias) in the value / gate interleaved row order
+    dc_igemm's GEGLU epilogue expects, optionally with a LayerNorm (gamma, beta) folded in (dc_pack_weights_geglu)."""
+    wd, bd = _dev32(w, device), _dev32(b, device)
+    cout, K = wd.shape
+    out = _packed(L.lib().dc_igemm_cout_pad(cout, 128), K, dt, device)
+    ob = torch.empty(cout, dtype=torch.float32, device=device)
+    ws = torch.empty(cout, dtype=torch.int32, device=device)
+    g = None if ln_gamma is None else _dev32(ln_gamma, device)
+    be = None if ln_beta is None else _dev32(ln_beta, device)
+    L.check(L.lib().dc_pack_weights_geglu(wd.data_ptr(), bd.data_ptr(), cout // 2, K, None if g is None else g.data_ptr(),
+                                          None if be is None else be.data_ptr(), out.data_ptr(), ob.data_ptr(), ws.data_ptr(), dt,
+                                          L.stream_ptr()), "dc_pack_weights_geglu")
+    return out, ob
+
+
+def fold_layernorm_bias(w, bias, ln_beta, device):
+    """W beta (+ bias): the bias of a GEMM that absorbed a LayerNorm's beta (dc_fold_layernorm_bias)."""
+    wd, be = _dev32(w, device), _dev32(ln_beta, device)
+    bd = None if bias is None else _dev32(bias, device)
+    out = torch.empty(wd.shape[0], dtype=torch.float32, device=device)
+    L.check(L.lib().dc_fold_layernorm_bias(wd.data_ptr(), None if bd is None else bd.data_ptr(), be.data_ptr(), wd.shape[0], wd.shape[1],
+                                           out.data_ptr(), L.stream_ptr()), "dc_fold_layernorm_bias")
+    return out
 
 
 def geglu_perm(n_half):
-    """Row order of the packed GEGLU projection: 16-row blocks alternate value / gate halves."""
+    """Row order of the packed GEGLU projection (what dc_pack_weights_geglu applies): 16-row blocks alternate value / gate halves.
+    Kept as the executable statement of that layout for the tests."""
     assert n_half % 16 == 0
     idx = []
     for b in range(n_half // 16):
@@ -485,7 +510,7 @@ class UNetWeights:
 
         def conv1(key):
             w = sd[key + ".weight"]
-            P[key + ".w"] = pack_matrix(w.reshape(w.shape[0], -1), dt, device)
+            P[key + ".w"] = pack_matrix(w, dt, device)
             P[key + ".b"] = f32c(sd[key + ".bias"], device)
 
         def lin(key, dtype=None, bias=True):
@@ -530,10 +555,8 @@ class UNetWeights:
             qkv = torch.cat([sd[tb_ + f".attn1.to_{n}.weight"] for n in "qkv"], 0)
             P[tb_ + ".qkv.w"] = pack_matrix(qkv, dt, device)
             lin(tb_ + ".attn1.to_out.0")
-            pw, pb = sd[tb_ + ".ff.net.0.proj.weight"], sd[tb_ + ".ff.net.0.proj.bias"]
-            perm = geglu_perm(pw.shape[0] // 2)
-            P[tb_ + ".ff.net.0.proj.w"] = pack_matrix(pw[perm], dt, device)
-            P[tb_ + ".ff.net.0.proj.b"] = f32c(pb[perm], device)
+            P[tb_ + ".ff.net.0.proj.w"], P[tb_ + ".ff.net.0.proj.b"] = pack_geglu(
+                sd[tb_ + ".ff.net.0.proj.weight"], sd[tb_ + ".ff.net.0.proj.bias"], dt, device)
             lin(tb_ + ".ff.net.2")
             # class-token side path (fp32): to_v then to_out of attn2 (to_q/to_k never matter for 1 key)
             lin(tb_ + ".attn2.to_out.0", L.DC_F32)
@@ -555,8 +578,8 @@ class UNetWeights:
         P, sd = self.P, self._sd
         if key + ".conv1.wa" not in P:
             w = sd[key + ".conv1.weight"]
-            P[key + ".conv1.wa"] = pack_conv3x3(w[:, :C0], self.dt, self.dev)
-            P[key + ".conv1.wb"] = pack_conv3x3(w[:, C0:], self.dt, self.dev)
+            P[key + ".conv1.wa"] = pack_conv3x3(w, self.dt, self.dev, c_lo=0, c_hi=C0)
+            P[key + ".conv1.wb"] = pack_conv3x3(w, self.dt, self.dev, c_lo=C0)
             if key + ".conv_shortcut.weight" in sd:
                 ws = sd[key + ".conv_shortcut.weight"]
                 ws = ws.reshape(ws.shape[0], -1)
@@ -571,15 +594,12 @@ class UNetWeights:
         P, sd = self.P, self._sd
         if tb_ + ".qkv.wf" in P:
             return P
-        g1, b1 = sd[tb_ + ".norm1.weight"].float(), sd[tb_ + ".norm1.bias"].float()
         qkv = torch.cat([sd[tb_ + f".attn1.to_{n}.weight"] for n in "qkv"], 0).float()
-        P[tb_ + ".qkv.wf"] = pack_matrix(qkv * g1[None, :], self.dt, self.dev)
-        P[tb_ + ".qkv.bf"] = f32c(qkv @ b1, self.dev)
-        g3, b3 = sd[tb_ + ".norm3.weight"].float(), sd[tb_ + ".norm3.bias"].float()
-        pw, pb = sd[tb_ + ".ff.net.0.proj.weight"].float(), sd[tb_ + ".ff.net.0.proj.bias"].float()
-        perm = geglu_perm(pw.shape[0] // 2)
-        P[tb_ + ".ff.net.0.proj.wf"] = pack_matrix((pw * g3[None, :])[perm], self.dt, self.dev)
-        P[tb_ + ".ff.net.0.proj.bf"] = f32c((pb + pw @ b3)[perm], self.dev)
+        P[tb_ + ".qkv.wf"] = pack_matrix(qkv, self.dt, self.dev, col_scale=sd[tb_ + ".norm1.weight"])
+        P[tb_ + ".qkv.bf"] = fold_layernorm_bias(qkv, None, sd[tb_ + ".norm1.bias"], self.dev)
+        P[tb_ + ".ff.net.0.proj.wf"], P[tb_ + ".ff.net.0.proj.bf"] = pack_geglu(
+            sd[tb_ + ".ff.net.0.proj.weight"], sd[tb_ + ".ff.net.0.proj.bias"], self.dt, self.dev,
+            ln_gamma=sd[tb_ + ".norm3.weight"], ln_beta=sd[tb_ + ".norm3.bias"])
         return P
 
     def nbytes(self):

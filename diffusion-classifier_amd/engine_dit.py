@@ -20,9 +20,7 @@ class DiTWeights:
         p, cin = cfg.patch_size, cfg.in_channels
         self.kin = round_up(cin * p * p, bke(dt))
         w = sd["pos_embed.proj.weight"].reshape(model.D, cin * p * p)        # k = c*p*p + py*p + px
-        wp = torch.zeros(model.D, self.kin)
-        wp[:, : cin * p * p] = w
-        P["patch.w"] = pack_matrix(wp, dt, device)
+        P["patch.w"] = pack_matrix(w, dt, device, kpad=self.kin)
         P["patch.b"] = f32c(sd["pos_embed.proj.bias"], device)
         P["pos"] = model.pos_embed.pos_embed.detach().to(device=device, dtype=TORCH_DT[dt]).reshape(-1, model.D).contiguous()
         nl = cfg.num_layers

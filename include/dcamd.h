@@ -15,6 +15,10 @@
  *   dc_attention        F.scaled_dot_product_attention self-attention (attn1)
  *   dc_eps_mse          diffusion_classifier.py:706-711 (v->eps, torch.norm(...)**2)
  *   dc_haar_dwt2/idwt2  utils/wavelet.py:4-35 / :37-68
+ *   dc_stage_topk / dc_reduce_argmin / dc_stage_maps
+ *                       the stage end, diffusion_classifier.py:718-725 (mean over trials, k smallest classes) and the
+ *                       per-image surviving-class lists of the next stage (:695-698, ragged after pruning / fast mode
+ *                       :671-677) as device-side work-unit maps
  *   dc_run_plan         the Python double loop body, diffusion_classifier.py:695-714, as
  *                       one native launch sequence (graph-capturable)
  *
@@ -138,6 +142,33 @@ int32_t dc_igemm_qstats_parts(const dc_igemm_params* p);
 /* 1 when dc_igemm can take up4 = 1 (four-phase upsample conv) for this problem. */
 int32_t dc_igemm_up4_ok(const dc_igemm_params* p);
 
+/* ---------------------------------------------------------------- weight packing - */
+/* dc_igemm consumes weights as [Cout_pad][K] in the compute dtype, K contiguous, rows zero-padded to the N tile
+ * (Cout_pad = dc_igemm_cout_pad(cout, tile_n)).  These entry points build that form on the device from the framework's fp32
+ * parameter tensors (device pointers, row-major, diffusers layouts); run once per (weights, dtype).  All buffers caller-owned;
+ * dc_packed_bytes gives the size of a packed [Cout_pad][K] buffer.
+ *   matrix   Linear / Conv2d 1x1 weight [cout, K]: out[r][k] = w[row_perm ? row_perm[r] : r][k] * (col_scale ? col_scale[k] : 1),
+ *            columns K..kpad-1 zero (kpad >= K: conv_in's K = 9*Cin is padded to the 128-byte K granule).  col_scale folds a
+ *            LayerNorm gamma into the consumer GEMM (dc_igemm ln_eps); dc_fold_layernorm_bias gives the matching bias W beta + c.
+ *   conv3x3  Conv2d weight [cout, cin, 3, 3], input-channel slice [c_lo, c_hi): out[r][tap*C + c], tap = ky*3 + kx, C = c_hi - c_lo
+ *            (a slice: the two halves of a skip-connection conv, conv(cat(a, b)) = conv_a(a) + conv_b(b)).
+ *   up4      the four-phase form of "nearest-2x upsample, then 3x3 conv" (dc_igemm_params.up4): out[2a+b][r][(dy*2+dx)*cin + c] =
+ *            fp32 sum of the 3x3 taps that read source pixel (y+a-1+dy, x+b-1+dx) — rows a=0: {k0} | {k1,k2}, a=1: {k0,k1} | {k2},
+ *            columns alike; buffer = 4 x dc_packed_bytes(cout, 4*cin).
+ *   geglu    GEGLU projection [2*n_half, K] (+ bias [2*n_half]): packed row 32*blk + i = value row 16*blk + i (i < 16), gate row
+ *            n_half + 16*blk + i - 16 otherwise, so value and gate of a channel meet in one lane of the epilogue; optional LayerNorm
+ *            fold (gamma into the columns, out_bias = permuted (bias + W beta)); perm_ws: int32[2*n_half] scratch. */
+int64_t dc_packed_bytes(int32_t cout, int32_t K, int32_t dtype, int32_t tile_n);
+int dc_pack_weights_matrix(const float* w, int32_t cout, int32_t K, int32_t kpad, const int32_t* row_perm, const float* col_scale,
+                           void* out, int32_t dtype, int32_t tile_n, dc_stream s);
+int dc_pack_weights_conv3x3(const float* w, int32_t cout, int32_t cin, int32_t c_lo, int32_t c_hi, int32_t kpad, void* out,
+                            int32_t dtype, int32_t tile_n, dc_stream s);
+int dc_pack_weights_up4(const float* w, int32_t cout, int32_t cin, void* out, int32_t dtype, int32_t tile_n, dc_stream s);
+int dc_pack_weights_geglu(const float* w, const float* bias, int32_t n_half, int32_t K, const float* ln_gamma, const float* ln_beta,
+                          void* out_w, float* out_bias, int32_t* perm_ws, int32_t dtype, dc_stream s);
+/* out_bias[r] = (bias ? bias[r] : 0) + sum_k w[r][k] * ln_beta[k]   (fp32, k ascending) */
+int dc_fold_layernorm_bias(const float* w, const float* bias, const float* ln_beta, int32_t cout, int32_t K, float* out_bias, dc_stream s);
+
 /* ---------------------------------------------------------------- norms ---------- */
 /* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.
  * ws: float workspace >= dc_groupnorm_ws_floats(n, groups, splits). */
@@ -158,6 +189,9 @@ typedef struct {
 int dc_groupnorm(const dc_groupnorm_params* p, dc_stream s);
 int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t splits);
 int32_t dc_groupnorm_splits(int32_t n, int32_t HW, int32_t C);
+/* Workspace bytes per op (only GroupNorm needs one; the others keep everything in registers / LDS and return 0). */
+int64_t dc_workspace_bytes_groupnorm(const dc_groupnorm_params* p);
+int64_t dc_workspace_bytes_igemm(const dc_igemm_params* p);
 
 /* LayerNorm over C per row. gamma/beta may be NULL.  If scale/shift given (adaLN):
  * y = ln(x)*(1+scale[m[n]][c]) + shift[m[n]][c], n = row / rows_per_sample. */
@@ -168,6 +202,7 @@ typedef struct {
   const float* scale; const float* shift; const int32_t* mod_map;
 } dc_layernorm_params;
 int dc_layernorm(const dc_layernorm_params* p, dc_stream s);
+int64_t dc_workspace_bytes_layernorm(const dc_layernorm_params* p);
 
 /* ---------------------------------------------------------------- attention ------ */
 /* softmax(q k^T * scale) v per (sample, head).  q/k/v: [n, L, heads, d] with row stride
@@ -177,6 +212,7 @@ typedef struct {
   int32_t dtype, n, L, heads, d, ld_qkv, ld_out; float scale;
 } dc_attention_params;
 int dc_attention(const dc_attention_params* p, dc_stream s);
+int64_t dc_workspace_bytes_attention(const dc_attention_params* p);
 
 /* ---------------------------------------------------------------- eps-MSE -------- */
 /* err[u] = (|| eps_hat_u - eps_{bj(u)} ||_2)^2 over C*H*W   (reference :706-711)
@@ -197,6 +233,20 @@ int dc_eps_mse(const dc_eps_mse_params* p, dc_stream s);
 int dc_haar_dwt2(const float* in, float* out, int32_t n, int32_t C, int32_t H, int32_t W, float scale, dc_stream s);
 /* in [n, 4C, h, w] -> out [n, C, 2h, 2w] */
 int dc_haar_idwt2(const float* in, float* out, int32_t n, int32_t C, int32_t h, int32_t w, float scale, dc_stream s);
+
+/* ---------------------------------------------------------------- stage end ------ */
+/* errors [BS, C, T] f32 (+inf = cell not evaluated).  mean[b, c] = (sum_{j < t_end} errors[b, c, j]) / t_end, fp32, j ascending
+ * (a fixed order: identical on every rank and for every world size).  keep[b, 0..k) = the k classes of smallest mean, ascending,
+ * ties to the lower class id (reference: torch.topk(mean, k, largest=False), :720-721).  means [BS, C] optional (NULL). C <= 1024. */
+int dc_stage_topk(const float* errors, int32_t BS, int32_t C, int32_t T, int32_t t_end, int32_t k, int32_t* keep, float* means, dc_stream s);
+/* The last stage (k = 1): labels[b] = arg-min class as int64 (the LongTensor classify returns, :725). */
+int dc_reduce_argmin(const float* errors, int32_t BS, int32_t C, int32_t T, int32_t t_end, int64_t* labels, float* means, dc_stream s);
+/* Next stage's work-unit maps from keep[BS, k]: this rank's r-th pair is global pair g = rank + r*world of the stage, trial
+ * j = t0 + g / BS, image b = g % BS; micro-batch m = pairs [m*n_bj, (m+1)*n_bj) (n_mb = ceil(n_pairs / n_bj)); slots past n_pairs
+ * repeat the micro-batch's first pair and score into cell `dump`.  maps[m] = | ctx_of_unit[n_bj*k] | out_index[n_bj*k] | (int32):
+ * class id of each unit and the flat index of errors[b, class, j] it writes (dc_eps_mse out_index). */
+int dc_stage_maps(const int32_t* keep, int32_t BS, int32_t C, int32_t T, int32_t k, int32_t t0, int32_t n_pairs, int32_t rank,
+                  int32_t world, int32_t n_bj, int32_t n_mb, int32_t dump, int32_t* maps, dc_stream s);
 
 /* ---------------------------------------------------------------- plan ----------- */
 typedef enum { DC_OP_QSAMPLE = 1, DC_OP_SINUSOID = 2, DC_OP_IGEMM = 3, DC_OP_GROUPNORM = 4,

@@ -684,3 +684,122 @@ def test_upsample_conv_as_four_phases(dt, shape):
     assert torch.isfinite(qs).all()
     assert (tot[..., 0] - s_ref).abs().max().item() < 2e-3 * max(1.0, s_ref.abs().max().item())
     assert (tot[..., 1] - q_ref).abs().max().item() < (1e-4 if dt == L.DC_F32 else 2e-3) * q_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(5, 10, 50, 50, 3), (3, 6, 7, 3, 2), (2, 100, 9, 9, 1), (4, 1000, 4, 2, 7)])
+def test_stage_topk_and_argmin_match_torch(shape):
+    """dc_stage_topk / dc_reduce_argmin: mean over the evaluated trials + k smallest classes per image (reference
+    diffusion_classifier.py:718-721), unevaluated (+inf) classes never kept."""
+    BS, Cn, T, t_end, k = shape
+    torch.manual_seed(41)
+    err = torch.rand(BS, Cn, T) * 100 + 1000
+    dead = torch.rand(BS, Cn) < 0.3
+    dead[:, : k + 1] = False                                   # at least k + 1 live classes per image
+    err[dead] = float("inf")
+    lib = L.lib()
+    e = err.to(DEV)
+    keep = torch.full((BS, k), -1, dtype=torch.int32, device=DEV)
+    means = torch.zeros(BS, Cn, device=DEV)
+    L.check(lib.dc_stage_topk(ptr(e), BS, Cn, T, t_end, k, ptr(keep), ptr(means), L.stream_ptr()), "dc_stage_topk")
+    ref_mean = err[:, :, :t_end].mean(2)
+    ref_keep = torch.topk(ref_mean, k, dim=1, largest=False).indices
+    fin = torch.isfinite(ref_mean)
+    assert torch.equal(torch.isfinite(means.cpu()), fin)
+    assert ((means.cpu()[fin] - ref_mean[fin]).abs() / ref_mean[fin]).max().item() < 1e-6
+    assert torch.equal(keep.cpu().long(), ref_keep)
+    lab = torch.full((BS,), -1, dtype=torch.int64, device=DEV)
+    L.check(lib.dc_reduce_argmin(ptr(e), BS, Cn, T, t_end, ptr(lab), None, L.stream_ptr()), "dc_reduce_argmin")
+    assert torch.equal(lab.cpu(), ref_mean.argmin(1))
+    # exact ties go to the lower class id
+    e2 = torch.full((2, 5, 3), 7.0, device=DEV)
+    k2 = torch.zeros((2, 3), dtype=torch.int32, device=DEV)
+    L.check(lib.dc_stage_topk(ptr(e2), 2, 5, 3, 3, 3, ptr(k2), None, L.stream_ptr()), "dc_stage_topk")
+    assert k2.cpu().tolist() == [[0, 1, 2], [0, 1, 2]]
+    assert lib.dc_stage_topk(ptr(e), BS, Cn, T, t_end, Cn + 1, ptr(keep), None, L.stream_ptr()) == -2     # k > classes
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (3, 1)])
+def test_stage_maps_match_the_host_built_control_blocks(world, rank):
+    """dc_stage_maps: next stage's (pair, class) -> work-unit maps from the surviving classes, against the index arithmetic
+    classify does on the host for stage 0 (diffusion_classifier.py _HipRunner.run_stage)."""
+    from diffusion_classifier_amd import dist as D
+    BS, Cn, T, k, t0, t1, n_bj = 5, 9, 12, 3, 4, 12, 7
+    torch.manual_seed(43)
+    keep = torch.stack([torch.randperm(Cn)[:k] for _ in range(BS)]).to(torch.int32)
+    pairs = D.local_pairs(t0, t1, BS, rank, world)
+    n_mb = -(-len(pairs) // n_bj)
+    U, dump = n_bj * k, BS * Cn * T
+    maps = torch.full((n_mb, 2 * U), -7, dtype=torch.int32, device=DEV)
+    kd = keep.to(DEV)
+    L.check(L.lib().dc_stage_maps(ptr(kd), BS, Cn, T, k, t0, len(pairs), rank, world, n_bj, n_mb, dump, ptr(maps), L.stream_ptr()), "dc_stage_maps")
+    got = maps.cpu()
+    for m in range(n_mb):
+        chunk = pairs[m * n_bj:(m + 1) * n_bj]
+        pad = n_bj - len(chunk)
+        js = torch.tensor([p[0] for p in chunk] + [chunk[0][0]] * pad)
+        bs = torch.tensor([p[1] for p in chunk] + [chunk[0][1]] * pad)
+        cl = keep[bs].long()
+        oi = (bs[:, None] * Cn + cl) * T + js[:, None]
+        if pad:
+            oi[len(chunk):] = dump
+        assert torch.equal(got[m, :U].long(), cl.reshape(-1)) and torch.equal(got[m, U:].long(), oi.reshape(-1))
+
+
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+def test_weight_packers_match_their_documented_layouts(dt):
+    """dc_pack_weights_{matrix,conv3x3,up4,geglu} / dc_fold_layernorm_bias (include/dcamd.h "weight packing") against the same
+    layouts written out in torch: bit-exact (the only arithmetic is the fp32 tap sums of up4 and the LayerNorm folds)."""
+    torch.manual_seed(61)
+    td = TD[dt]
+    lib = L.lib()
+    # matrix: row padding to the N tile, column padding, gamma folded into the columns
+    w = torch.randn(200, 72)
+    got = E.pack_matrix(w, dt, DEV, kpad=96).cpu()
+    ref = torch.zeros(256, 96)
+    ref[:200, :72] = w
+    assert got.shape == (256, 96) and torch.equal(got, ref.to(td))
+    assert lib.dc_packed_bytes(200, 96, dt, 128) == got.numel() * got.element_size()
+    gam = torch.randn(72)
+    assert torch.equal(E.pack_matrix(w, dt, DEV, col_scale=gam).cpu()[:200], (w * gam[None, :]).to(td))
+    assert tuple(E.pack_matrix(w[:5], dt, DEV, tile_n=32).shape) == (32, 72)
+    # conv3x3: k = tap * C + c, channel slices for split skip-connection convs
+    wc = torch.randn(40, 24, 3, 3)
+    full = wc.permute(0, 2, 3, 1).reshape(40, 9 * 24)
+    g3 = E.pack_conv3x3(wc, dt, DEV, kpad=256).cpu()
+    assert g3.shape == (128, 256) and torch.equal(g3[:40, :216], full.to(td)) and not g3[40:].any() and not g3[:, 216:].any()
+    lo = E.pack_conv3x3(wc, dt, DEV, c_lo=0, c_hi=8).cpu()
+    hi = E.pack_conv3x3(wc, dt, DEV, c_lo=8).cpu()
+    assert torch.equal(lo[:40], wc[:, :8].permute(0, 2, 3, 1).reshape(40, 72).to(td))
+    assert torch.equal(hi[:40], wc[:, 8:].permute(0, 2, 3, 1).reshape(40, 144).to(td))
+    # up4: phase-summed 2x2 taps, summed in fp32 before rounding
+    sets = (((0,), (1, 2)), ((0, 1), (2,)))
+    phases = []
+    for a in range(2):
+        for b in range(2):
+            taps = []
+            for dy in range(2):
+                for dx in range(2):
+                    acc = 0
+                    for ky in sets[a][dy]:
+                        for kx in sets[b][dx]:
+                            acc = acc + wc[:, :, ky, kx]
+                    taps.append(acc)
+            phases.append(torch.cat(taps, 1))
+    g4 = E.pack_up4(wc, dt, DEV).cpu()
+    assert g4.shape == (4, 128, 96) and torch.equal(g4[:, :40], torch.stack(phases).to(td)) and not g4[:, 40:].any()
+    # GEGLU: value / gate rows interleaved in 16-row blocks, with and without the LayerNorm fold
+    nh, K = 48, 64
+    wg, bg = torch.randn(2 * nh, K), torch.randn(2 * nh)
+    perm = E.geglu_perm(nh)
+    pw, pb = E.pack_geglu(wg, bg, dt, DEV)
+    assert torch.equal(pw.cpu()[:2 * nh], wg[perm].to(td)) and torch.equal(pb.cpu(), bg[perm])
+    gam, bet = torch.randn(K), torch.randn(K)
+    pwf, pbf = E.pack_geglu(wg, bg, dt, DEV, ln_gamma=gam, ln_beta=bet)
+    assert torch.equal(pwf.cpu()[:2 * nh], (wg * gam[None, :])[perm].to(td))
+    assert (pbf.cpu() - (bg + wg @ bet)[perm]).abs().max().item() < 1e-4
+    fb = E.fold_layernorm_bias(wg, None, bet, DEV).cpu()
+    assert (fb - wg @ bet).abs().max().item() < 1e-4
+    # workspace queries
+    gp = L.GroupnormParams(n=3, HW=64, C=128, C1=0, groups=32, splits=0)
+    assert lib.dc_workspace_bytes_groupnorm(gp) == 4 * lib.dc_groupnorm_ws_floats(3, 32, lib.dc_groupnorm_splits(3, 64, 128))
+    assert lib.dc_workspace_bytes_igemm(L.IgemmParams()) == 0 and lib.dc_workspace_bytes_attention(L.AttentionParams()) == 0
