@@ -58,6 +58,10 @@ struct HaloGeom {
   // other's MFMA loop.  mode 0: off; 1: second arrival on a CU (per-CU arrival counter keyed by the hardware CU id);
   // 2: blocks [256, 512); 3: odd blocks below 512; 4: pseudo-random delay below stagger_cyc for blocks below 512.
   int stagger_mode, stagger_cyc;
+  // xbuf: one image per patch and every source image below 2 GiB -> the halo pieces are fetched through per-image buffer
+  // descriptors (buffer_load ... lds: 32-bit per-lane offset, hardware range check = zero padding) instead of 64-bit
+  // per-lane addresses + zero page: ~6 VALU per chunk instead of ~150.
+  int xbuf;
 };
 
 static __device__ unsigned g_cu_arrivals[4096];     // per hardware CU: workgroups of this library seen so far (parity = stagger role)
@@ -108,7 +112,9 @@ template <int V> struct IC { static constexpr int value = V; };
 // (2y+pa, 2x+pb) only sees the 2x2 source pixels (y+pa-1+dy, x+pb-1+dx), with the 3x3 taps that fall on the same source
 // pixel summed when the weights are packed — 4 taps instead of 9, the same halo of the LOW-resolution image; the four
 // phases are four times the N tiles of the grid (g.* then describes the low-resolution image).
-template <typename T, int NW, bool GN, int NTAP = 9>
+// XB: buffer-descriptor loaders (HaloGeom::xbuf: one image per patch) — a separate instantiation, so that neither form carries
+// the other's registers (the kernel sits at the SGPR / VGPR limits of two waves per SIMD)
+template <typename T, int NW, bool GN, int NTAP = 9, bool XB = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
   using Cfg = HaloCfg<NW>;
   constexpr int EPC = Elem<T>::EPC;
@@ -234,8 +240,47 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     }
   };
 
+  // ---- XB: buffer descriptors (wave-uniform by construction: kernel arguments and blockIdx only).  All four share the range
+  // (2 GiB - 1: every real offset is below it by the host's checks) and the format word, so only the bases differ.
+  // W: per-lane offset = the lane's (row, chunk) inside an N tile — ONE register for the whole kernel — and the (N tile, tap,
+  // channel chunk) part in the scalar offset: no vector arithmetic per tap.  X: based at the patch's image of each source; a
+  // padding piece gets offset 0xffffffff (out of range: the hardware returns zeros).
+  const T* xb0 = nullptr; const T* xb1 = nullptr; const T* xb2 = nullptr;
+  int wvoff = 0, ldb0 = 0, ldb1 = 0, ldb2 = 0;
+  if (XB) {
+    ldb0 = a.ld0 * (int)sizeof(T); ldb1 = a.ld1 * (int)sizeof(T); ldb2 = a.ld2 * (int)sizeof(T);
+    asm volatile("" : "+s"(ldb0), "+s"(ldb1), "+s"(ldb2));
+    const int n = ng;
+    const int s0 = __builtin_amdgcn_readfirstlane(a.map0 ? a.map0[n] : n);
+    xb0 = reinterpret_cast<const T*>(a.src0) + (size_t)s0 * HWs * a.ld0;
+    if (a.src1) { const int s1 = __builtin_amdgcn_readfirstlane(a.map1 ? a.map1[n] : n); xb1 = reinterpret_cast<const T*>(a.src1) + (size_t)s1 * HWs * a.ld1; }
+    if (a.src2) { const int s2 = __builtin_amdgcn_readfirstlane(a.map2 ? a.map2[n] : n); xb2 = reinterpret_cast<const T*>(a.src2) + (size_t)s2 * HWs * a.ld2; }
+    const int wrow0 = t >> 2;                        // LDS row of the lane's first piece (piece i is 64 rows further when NT == 256)
+    wvoff = (epi_wrow(wrow0, false) * a.Ktot + ((t & 3) ^ swz64(wrow0)) * EPC) * (int)sizeof(T);
+  }
+  auto rsrc_of = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
+
   auto issue_x = [&](int cc) {                       // cc >= nchunks: chunk cc - nchunks of the 1x1 side source
     const int which = cc >= nchunks ? 2 : (cc >= c0chunks ? 1 : 0);
+    if constexpr (XB) {
+      // (selected from LOCAL copies: a select between fields of the by-value argument struct becomes a select of their addresses,
+      //  which moves the whole struct into scratch)
+      int ldb = ldb0, cb = cc;
+      const T* xb = xb0;
+      if (cc >= nchunks) { ldb = ldb2; cb = cc - nchunks; xb = xb2; }
+      else if (cc >= c0chunks) { ldb = ldb1; cb = cc - c0chunks; xb = xb1; }
+      const int cofs = cb * 64 + xlx * 16;
+      const __amdgpu_buffer_rsrc_t rs = rsrc_of(xb);
+      char* xs = smem + (cc & 1) * Cfg::XBUF + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) {
+        int pk = pp[i];
+        asm volatile("" : "+v"(pk));      // form the offset HERE, once per chunk (hoisted it would cost a register per piece)
+        const int voff = pk < 0 ? -1 : pk * ldb + cofs;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(xs + i * (NT * 16)), 16, voff, 0, 0, 0);
+      }
+      return;
+    } else {
     const T* src = reinterpret_cast<const T*>(which == 2 ? a.src2 : (which == 1 ? a.src1 : a.src0));
     const int ld = which == 2 ? a.ld2 : (which == 1 ? a.ld1 : a.ld0);
     const int coff = (which == 2 ? cc - nchunks : (which == 1 ? cc - c0chunks : cc)) * BKE + xlx * EPC;
@@ -251,21 +296,31 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       const char* gp = base < 0 ? zero : reinterpret_cast<const char*>(src + e);
       __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
     }
+    }
   };
   // ---- W loader: 128 couts x 64 B per (chunk, tap): position i*NT + t -> row >>2, phys chunk &3 (swizzled) ----
   // element offset of the lane's W row chunk from the tile's first row (32-bit: Cout_pad*Ktot < 2^31), recomputed at every
   // issue from an opaque copy of t (a handful of VALU per tap) instead of living in VGPRs through the tap loop
+  const int wtile0 = ((UP4 ? phase * (a.tiles_n >> 2) : 0) + tile_n) * 128 * a.Ktot;    // element offset of the N tile (up4: [phase][Cout_pad][4 taps * C]); < 2^30 (host check)
   auto issue_w = [&](int cc, int tap, int slot) {
-    const T* wb = reinterpret_cast<const T*>(a.W) + (size_t)((UP4 ? phase * (a.tiles_n >> 2) : 0) + tile_n) * 128 * a.Ktot +
-                  (size_t)tap * Ctot + (size_t)cc * BKE;   // wave-uniform; up4: [phase][Cout_pad][4 taps * C]
-    int tt = t;
-    asm volatile("" : "+v"(tt));
+    if constexpr (XB) {
+      const int so = (wtile0 + tap * Ctot + cc * BKE) * (int)sizeof(T);                  // wave-uniform: scalar offset
+      const __amdgpu_buffer_rsrc_t wrs = rsrc_of(a.W);
 #pragma unroll
-    for (int i = 0; i < WLD; ++i) {
-      const int row = (i * NT + tt) >> 2;
-      const int wro = epi_wrow(row, false) * a.Ktot + ((tt & 3) ^ swz64(row)) * EPC;
-      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wb + wro),
-                                       (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
+      for (int i = 0; i < WLD; ++i)    // piece i: LDS rows 64 i + (t >> 2) = packed rows 64 further (epi_wrow and the swizzle keep the low part)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, wvoff,
+                                                 so + i * 64 * a.Ktot * (int)sizeof(T), 0, 0);
+    } else {
+      const T* wb = reinterpret_cast<const T*>(a.W) + (size_t)wtile0 + (size_t)tap * Ctot + (size_t)cc * BKE;   // wave-uniform
+      int tt = t;
+      asm volatile("" : "+v"(tt));     // recomputed at every issue from an opaque copy of t instead of living in VGPRs through the tap loop
+#pragma unroll
+      for (int i = 0; i < WLD; ++i) {
+        const int row = (i * NT + tt) >> 2;
+        const int wro = epi_wrow(row, false) * a.Ktot + ((tt & 3) ^ swz64(row)) * EPC;
+        __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wb + wro),
+                                         (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -601,6 +656,8 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
                                                   : (a0.gn_scale ? conv3_halo_kernel<T, NW, true> : conv3_halo_kernel<T, NW, false>);
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_done = true;
   }
   IgemmArgs a = a0;
@@ -631,11 +688,20 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   const long long steps = (long long)((a.C0 + a.C1) / (64 / (int)sizeof(T))) * (up4 ? 4 : 9) + (a.src2 ? a.C2 / (64 / (int)sizeof(T)) : 0);
   g.stagger_mode = NW == 4 ? st_mode : 0;
   g.stagger_cyc = (int)((steps * 1300 + 20000) * st_pct / 100);
+  static const bool no_xbuf = getenv("DCAMD_HALO_NO_XBUF") != nullptr;
+  {
+    const long long hws = (long long)(a.upsample ? (g.H >> 1) * (g.W >> 1) : g.H * g.W);
+    const long long ldmax = a.ld0 > a.ld1 ? (a.ld0 > a.ld2 ? a.ld0 : a.ld2) : (a.ld1 > a.ld2 ? a.ld1 : a.ld2);
+    g.xbuf = (!no_xbuf && ni == 1 && !g.mos && !a.gn_scale && hws * ldmax * (long long)sizeof(T) < (1LL << 31) &&
+              (long long)a.tiles_n * 128 * a.Ktot * (long long)sizeof(T) < (1LL << 31)) ? 1 : 0;
+  }
+  if ((long long)a.tiles_n * 128 * a.Ktot >= (1LL << 31)) { dc_set_error("conv3_halo: weight matrix of %d x %d too large", a.tiles_n * 128, a.Ktot); return DC_ERR_SHAPE; }
   g.nxl = (g.HR * 4 + Cfg::NT - 1) / Cfg::NT;
   if (g.HR > Cfg::XROWS || g.nxl > Cfg::NXL || g.nxl < 3) { dc_set_error("conv3_halo: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
+  if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, true> : conv3_halo_kernel<T, NW, false, 9, true>;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
 }
@@ -699,7 +765,7 @@ static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
-  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.stagger_mode = 0; g.stagger_cyc = 0;
+  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.stagger_mode = 0; g.stagger_cyc = 0; g.xbuf = 0;
   g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + ThinCfg::NT - 1) / ThinCfg::NT;
   if (g.nxl > ThinCfg::NXL) { dc_set_error("conv3_thin: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }

@@ -98,7 +98,11 @@ def test_cifar_unet_forward_bf16():
     assert relerr(got, ref) < 1.5e-2, relerr(got, ref)          # measured 6.7e-3 (6.5e-3 with qstats / up4 switched off)
     plan = next(iter(m._plans.values()))
     fams = {mt.get("family", "") for mt in plan.pb.meta}
-    assert any(f.startswith("conv3_up4<bf16") for f in fams) and any(f.startswith("igemm_pipe_up4<bf16") for f in fams), fams
+    # the 8x8 -> 16x16 and 16x16 -> 32x32 upsample convs as four-phase halo convs; the 4x4 -> 8x8 one on mosaic halo patches too
+    # (on the tap-gather kernel when the mosaic is switched off)
+    import os
+    assert any(f.startswith("conv3_up4<bf16,4w") for f in fams) and any(f.startswith("conv3_up4<bf16,8w") for f in fams), fams
+    assert any(f.startswith("igemm_pipe_up4<bf16") for f in fams) == (os.environ.get("DCAMD_NO_MOSAIC") is not None), fams
     assert sum(1 for (_, _, f) in plan.pb.ops if "qparts" in f) >= 20
 
 
