@@ -52,19 +52,12 @@ struct HaloGeom {
   // (7 LDS-DMA pieces per lane) instead of 32 separate 6x6 halos (1152 rows, 9 pieces).  A tap is still one row offset.
   int mos, lmc;
   float inv_ch, inv_cw;     // 1/(th+1), 1/(tw+1)
-  // start stagger (speed only, never correctness): the workgroups of the first resident generation that share a CU start
-  // together and, doing equal work, stay in phase — prologue beside prologue, epilogue beside epilogue, for the whole launch.
-  // Delaying one of each pair by part of a tile's duration puts one workgroup's HBM-bound prologue / epilogue beside the
-  // other's MFMA loop.  mode 0: off; 1: second arrival on a CU (per-CU arrival counter keyed by the hardware CU id);
-  // 2: blocks [256, 512); 3: odd blocks below 512; 4: pseudo-random delay below stagger_cyc for blocks below 512.
-  int stagger_mode, stagger_cyc;
   // xbuf: one image per patch and every source image below 2 GiB -> the halo pieces are fetched through per-image buffer
   // descriptors (buffer_load ... lds: 32-bit per-lane offset, hardware range check = zero padding) instead of 64-bit
   // per-lane addresses + zero page: ~6 VALU per chunk instead of ~150.
   int xbuf;
 };
 
-static __device__ unsigned g_cu_arrivals[4096];     // per hardware CU: workgroups of this library seen so far (parity = stagger role)
 
 constexpr int HALO_WST = 128 * 64;                      // bytes per W tap tile
 
@@ -112,10 +105,13 @@ template <int V> struct IC { static constexpr int value = V; };
 // (2y+pa, 2x+pb) only sees the 2x2 source pixels (y+pa-1+dy, x+pb-1+dx), with the 3x3 taps that fall on the same source
 // pixel summed when the weights are packed — 4 taps instead of 9, the same halo of the LOW-resolution image; the four
 // phases are four times the N tiles of the grid (g.* then describes the low-resolution image).
-// XB: buffer-descriptor loaders (HaloGeom::xbuf: one image per patch) — a separate instantiation, so that neither form carries
-// the other's registers (the kernel sits at the SGPR / VGPR limits of two waves per SIMD)
-template <typename T, int NW, bool GN, int NTAP = 9, bool XB = false>
+// MODE: 0 = images of at least 8x8, per-lane 64-bit addresses; 1 (XB) = buffer-descriptor loaders (HaloGeom::xbuf: one image per
+// patch); 2 (MOS) = mosaic patches of images below 8x8 (HaloGeom::mos; a wave's pixels then span eight samples, so the epilogue
+// fetches the per-sample row vector per pixel fragment).  Separate instantiations, so that no form carries another's registers
+// (the kernel sits at the SGPR / VGPR limits of two waves per SIMD).
+template <typename T, int NW, bool GN, int NTAP = 9, int MODE = 0>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
+  constexpr bool XB = MODE == 1, MOS = MODE == 2;
   using Cfg = HaloCfg<NW>;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKE = 4 * EPC;                  // channels per 64-byte chunk row
@@ -128,27 +124,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  if (g.stagger_mode && blockIdx.x < 512) {
-    int cyc = 0;
-    if (g.stagger_mode == 1) {
-      int* flag = reinterpret_cast<int*>(smem);
-      if (t == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));     // HW_ID[15:8]: cu_id, sh_id, se_id
-        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID[3:0]
-        *flag = (int)(atomicAdd(&g_cu_arrivals[((xcc & 15) << 8) | (hw & 255)], 1u) & 1u);
-      }
-      __syncthreads();
-      cyc = *flag ? g.stagger_cyc : 0;
-      __syncthreads();
-    } else if (g.stagger_mode == 2) cyc = blockIdx.x >= 256 ? g.stagger_cyc : 0;
-    else if (g.stagger_mode == 3) cyc = (blockIdx.x & 1) ? g.stagger_cyc : 0;
-    else cyc = (int)((blockIdx.x * 2654435761u >> 8) % (unsigned)(g.stagger_cyc > 0 ? g.stagger_cyc : 1));
-    cyc = __builtin_amdgcn_readfirstlane(cyc);
-    if (cyc > 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)cyc) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   const int wm = wave >> 1, wn = wave & 1;      // NW/2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
@@ -186,21 +161,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     pp[i] = -1;
     if (i < g.nxl && hr < g.HR) {
       // hr < 2^12 and (hr + 0.5) / hp is at least 0.5 / hp away from an integer: the fp32 product floors exactly
-      if (g.mos) {
+      if constexpr (MOS) {
         // mosaic: halo position (hy, hx) -> grid cell (cy, cx) and position inside the cell; row / column 0 of a cell is a shared
         // zero separator (all quotients are < 2^10 and at least half a step away from an integer: the fp32 products floor exactly)
         const int hy = (int)(((float)hr + 0.5f) * g.inv_hw), hx = hr - hy * g.hw;
         const int cy = (int)(((float)hy + 0.5f) * g.inv_ch), ry = hy - cy * (th + 1);
         const int cx = (int)(((float)hx + 0.5f) * g.inv_cw), rx = hx - cx * (tw + 1);
         if (ry > 0 && rx > 0) pp[i] = (((cy << g.lmc) + cx) << 20) | ((ry - 1) * g.W + rx - 1);
-        continue;
-      }
+      } else {
       const int img = (int)(((float)hr + 0.5f) * g.inv_hp), r = hr - img * g.hp;
       const int hy = (int)(((float)r + 0.5f) * g.inv_hw), hx = r - hy * g.hw;
       const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
       // nearest-2x upsample folded into the gather: halo pixel (iy, ix) of the upsampled image reads source (iy>>1, ix>>1)
       if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
         pp[i] = (img << 20) | (a.upsample ? (iy >> 1) * (g.W >> 1) + (ix >> 1) : iy * g.W + ix);
+      }
     }
   }
   __syncthreads();
@@ -348,7 +323,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   for (int j = 0; j < TM; ++j) {
     const int p = wm * 128 + j * 16;
     const int img = p >> (g.ltw + g.lth), py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
-    const int o = g.mos ? ((img >> g.lmc) * (th + 1) + py) * g.hw + (img & ((1 << g.lmc) - 1)) * (tw + 1) + px : img * g.hp + py * g.hw + px;
+    const int o = MOS ? ((img >> g.lmc) * (th + 1) + py) * g.hw + (img & ((1 << g.lmc) - 1)) * (tw + 1) + px : img * g.hp + py * g.hw + px;
     joff[j] = __builtin_amdgcn_readfirstlane(o * 64);
   }
   const int woff0 = lds64_off(wn * 64 + lr, lq);
@@ -458,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   qsfn.np = HW >= 128 ? HW >> 7 : 1;
   qsfn.padd = 0;
   if (UP4) { qsfn.padd = phase * qsfn.np; qsfn.np *= 4; }       // every phase contributes its own parts of the output sample
-  epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, [&](int j, EpiRow& r) {
+  epi_direct_act<T, TM, DC_ACT_NONE, false, !MOS>(a, acc, tile_n, wn, lq, nw0, nw1, [&](int j, EpiRow& r) {
     const int p = wm * 128 + j * 16 + lr;
     int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
     r.ok = n < g.n_img;
@@ -656,8 +631,12 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
                                                   : (a0.gn_scale ? conv3_halo_kernel<T, NW, true> : conv3_halo_kernel<T, NW, false>);
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 9, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    if constexpr (NW == 8) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    }
     attr_done = true;
   }
   IgemmArgs a = a0;
@@ -681,13 +660,6 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
     g.inv_ch = 1.0f / (float)(th + 1); g.inv_cw = 1.0f / (float)(tw + 1);
   }
   g.inv_hp = g.hp ? 1.0f / (float)g.hp : 0.f; g.inv_hw = 1.0f / (float)g.hw;
-  static const int st_mode = getenv("DCAMD_HALO_STAGGER") ? atoi(getenv("DCAMD_HALO_STAGGER")) : 0;
-  static const int st_pct = getenv("DCAMD_HALO_STAGGER_PCT") ? atoi(getenv("DCAMD_HALO_STAGGER_PCT")) : 50;
-  // estimated lifetime of a tile in cycles (~1300 per tap step of a co-resident pair + ~20 k of prologue / epilogue); the delay is
-  // st_pct % of it.  Only when the grid has more than one resident generation and two workgroups share a CU (NW = 4).
-  const long long steps = (long long)((a.C0 + a.C1) / (64 / (int)sizeof(T))) * (up4 ? 4 : 9) + (a.src2 ? a.C2 / (64 / (int)sizeof(T)) : 0);
-  g.stagger_mode = NW == 4 ? st_mode : 0;
-  g.stagger_cyc = (int)((steps * 1300 + 20000) * st_pct / 100);
   static const bool no_xbuf = getenv("DCAMD_HALO_NO_XBUF") != nullptr;
   {
     const long long hws = (long long)(a.upsample ? (g.H >> 1) * (g.W >> 1) : g.H * g.W);
@@ -701,7 +673,8 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
-  if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, true> : conv3_halo_kernel<T, NW, false, 9, true>;
+  if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 1> : conv3_halo_kernel<T, NW, false, 9, 1>;
+  if constexpr (NW == 8) { if (g.mos) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 2> : conv3_halo_kernel<T, NW, false, 9, 2>; }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
 }
@@ -765,7 +738,7 @@ static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
-  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.stagger_mode = 0; g.stagger_cyc = 0; g.xbuf = 0;
+  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.xbuf = 0;
   g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + ThinCfg::NT - 1) / ThinCfg::NT;
   if (g.nxl > ThinCfg::NXL) { dc_set_error("conv3_thin: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }

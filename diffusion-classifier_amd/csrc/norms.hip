@@ -19,7 +19,6 @@ struct GnArgs {
   int C0, C1, HW, groups, silu, splits, out_dtype; float eps;
   const float* qstats; int qparts;      // statistics formed by the producer (dc_igemm_params.qstats): no statistics sweep
   int wsplits;                          // partial records per sample in ws (= splits, or 1 after gn_qfold_kernel)
-  int nt;                               // streaming hints of the one-sweep kernel: bit 0 non-temporal loads, bit 1 non-temporal stores
 };
 
 template <typename T>
@@ -252,17 +251,12 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
     return f_to_chunk<T>(f);
   };
   int p = pl;
-  const bool ntl = a.nt & 1, nts = a.nt & 2;
   for (; p + (UNR - 1) * PL < a.HW; p += UNR * PL) {
     chunk16 c[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) c[u] = ntl ? __builtin_nontemporal_load(src + (size_t)(p + u * PL) * pstride) : src[(size_t)(p + u * PL) * pstride];
+    for (int u = 0; u < UNR; ++u) c[u] = src[(size_t)(p + u * PL) * pstride];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const chunk16 o = norm(c[u]);
-      if (nts) __builtin_nontemporal_store(o, dst + (size_t)(p + u * PL) * ostride);
-      else dst[(size_t)(p + u * PL) * ostride] = o;
-    }
+    for (int u = 0; u < UNR; ++u) dst[(size_t)(p + u * PL) * ostride] = norm(c[u]);
   }
   for (; p < a.HW; p += PL) dst[(size_t)p * ostride] = norm(src[(size_t)p * pstride]);
 }
@@ -420,8 +414,6 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   a.C0 = p->C; a.C1 = C1; a.HW = p->HW; a.groups = p->groups; a.silu = p->silu; a.splits = p->splits;
   a.out_dtype = p->out_dtype; a.eps = p->eps;
   a.qstats = nullptr; a.qparts = 0; a.wsplits = p->splits;
-  static const int gn_nt = getenv("DCAMD_GN_NT") ? atoi(getenv("DCAMD_GN_NT")) : 0;
-  a.nt = gn_nt;
   if (p->qstats) {
     DC_REQUIRE(!stats_only && C1 == 0 && p->qparts > 0 && (C / p->groups) % 4 == 0 && ((uintptr_t)p->qstats & 7) == 0, DC_ERR_ARG,
                "dc_groupnorm: qstats needs one source, qparts > 0 and (C/groups) %% 4 == 0 (C=%d groups=%d C1=%d)", C, p->groups, C1);

@@ -65,7 +65,8 @@ class Bag:
 
 TINY = dict(sample_size=16, in_channels=3, out_channels=3, layers_per_block=1, block_out_channels=(32, 32),
             down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"), up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"),
-            mid_block_type="UNetMidBlock2DCrossAttn", encoder_hid_dim=32, encoder_hid_dim_type="text_proj", cross_attention_dim=32)
+            mid_block_type="UNetMidBlock2DCrossAttn", encoder_hid_dim=32, encoder_hid_dim_type="text_proj", cross_attention_dim=32,
+            attention_head_dim=2)      # 2 heads x 16 (diffusers reads this keyword as the head COUNT; libdcamd's attention needs head dim >= 16)
 CFG = dict(pred_param="eps", schedule="cosine", noise_d=16, image_size=16, cfg_w=0.0, ema_beta=0.999, ema_warmup=0,
            ema_update_freq=1, encoder_type="nn", classes=3, n_stages=1, evaluation_per_stage=[4], n_keep_per_stage=[1],
            n_fast_classes=2)
