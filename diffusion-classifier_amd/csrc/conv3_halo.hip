@@ -448,254 +448,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Persistent form of the buffer-descriptor kernel (HaloGeom::xbuf problems: one image per patch).  s_memtime stamps and the
-// K-dependence of the per-layer rates both put the cost of a tile at "taps + ~22 tap-times": index set-up, the first halo /
-// weight fetch at full HBM latency, the epilogue's loads, and the wait for its stores before the workgroup slot is re-used —
-// 38 % of a K = 1152 tile (the 32x32 and 16x16 levels of the UNets).  Here a workgroup walks tiles blockIdx.x, + gridDim.x, ...:
-// after the last tap of tile i it computes tile i+1's piece offsets and issues its first halo chunk and W groups into the LDS
-// slots the loop has already released, THEN runs tile i's epilogue, so those loads (and the index arithmetic) sit under the
-// epilogue, the epilogue's stores drain under tile i+1's first taps, and nothing is re-launched.  The LDS-DMA streams use
-// running chunk / step counters, so buffer parity and ring slots simply continue across tiles.
-template <typename T, int NW, int NTAP>
-__global__ __launch_bounds__(NW * 64, 2) void conv3_halo_pers_kernel(const IgemmArgs a, const HaloGeom g) {
-  using Cfg = HaloCfg<NW>;
-  constexpr int EPC = Elem<T>::EPC;
-  constexpr int BKE = 4 * EPC;
-  constexpr int TM = 8, TN = 4;
-  constexpr int NT = Cfg::NT, WLD = Cfg::WLD, WR = Cfg::WR, PD = Cfg::WR - 1, NXL = Cfg::NXL;
-  constexpr bool UP4 = NTAP == 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Wring = smem + 2 * Cfg::XBUF;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int tw = 1 << g.ltw, th = 1 << g.lth;
-  const int HW = g.H * g.W;
-  const int HWs = a.upsample ? (g.H >> 1) * (g.W >> 1) : HW;
-  const int Ctot = a.C0 + a.C1;
-  const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
-  const int nx = a.src2 ? a.C2 / BKE : 0;
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int xlx = t & 3;
-
-  // ---- tile descriptor (wave-uniform): N tile, up4 phase, patch position, image ----
-  struct TileD { int tile_n, phase, tx, ty, ng, wtile0; };
-  auto decode = [&](int tile) {
-    TileD d;
-    int tile_m;
-    tile_of_index(a, tile, ntiles, tile_m, d.tile_n);
-    d.phase = 0;
-    if (UP4) { const int tn = a.tiles_n >> 2; d.phase = d.tile_n / tn; d.tile_n -= d.phase * tn; }
-    d.tx = tile_m % g.tiles_x;
-    d.ty = (tile_m / g.tiles_x) % g.tiles_y;
-    d.ng = tile_m / (g.tiles_x * g.tiles_y);
-    d.wtile0 = ((UP4 ? d.phase * (a.tiles_n >> 2) : 0) + d.tile_n) * 128 * a.Ktot;
-    return d;
-  };
-
-  // ---- loaders (see conv3_halo_kernel, MODE 1): per-tile state = pp[] (piece -> pixel offset, -1 = padding), the three image
-  // bases and the N tile's weight offset ----
-  int pp[NXL];
-  const T* xb0 = nullptr; const T* xb1 = nullptr; const T* xb2 = nullptr;
-  int ldb0 = a.ld0 * (int)sizeof(T), ldb1 = a.ld1 * (int)sizeof(T), ldb2 = a.ld2 * (int)sizeof(T);
-  asm volatile("" : "+s"(ldb0), "+s"(ldb1), "+s"(ldb2));
-  const int wrow0 = t >> 2;
-  const int wvoff = (epi_wrow(wrow0, false) * a.Ktot + ((t & 3) ^ swz64(wrow0)) * EPC) * (int)sizeof(T);
-  int wtile0 = 0;
-  auto rsrc_of = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
-  auto setup_tile = [&](const TileD& d) {
-#pragma unroll
-    for (int i = 0; i < NXL; ++i) {
-      const int hr = (i * NT + t) >> 2;
-      pp[i] = -1;
-      if (i < g.nxl && hr < g.HR) {
-        const int hy = (int)(((float)hr + 0.5f) * g.inv_hw), hx = hr - hy * g.hw;       // one image per patch: hr = hy * hw + hx
-        const int iy = d.ty * th + hy - 1, ix = d.tx * tw + hx - 1;
-        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-          pp[i] = a.upsample ? (iy >> 1) * (g.W >> 1) + (ix >> 1) : iy * g.W + ix;
-      }
-    }
-    const int n = d.ng;
-    const int s0 = __builtin_amdgcn_readfirstlane(a.map0 ? a.map0[n] : n);
-    xb0 = reinterpret_cast<const T*>(a.src0) + (size_t)s0 * HWs * a.ld0;
-    if (a.src1) { const int s1 = __builtin_amdgcn_readfirstlane(a.map1 ? a.map1[n] : n); xb1 = reinterpret_cast<const T*>(a.src1) + (size_t)s1 * HWs * a.ld1; }
-    if (a.src2) { const int s2 = __builtin_amdgcn_readfirstlane(a.map2 ? a.map2[n] : n); xb2 = reinterpret_cast<const T*>(a.src2) + (size_t)s2 * HWs * a.ld2; }
-    wtile0 = d.wtile0;
-  };
-  auto issue_x = [&](int cc, int buf) {              // cc >= nchunks: chunk cc - nchunks of the 1x1 side source; buf: X buffer 0 / 1
-    int ldb = ldb0, cb = cc;
-    const T* xb = xb0;
-    if (cc >= nchunks) { ldb = ldb2; cb = cc - nchunks; xb = xb2; }
-    else if (cc >= c0chunks) { ldb = ldb1; cb = cc - c0chunks; xb = xb1; }
-    const int cofs = cb * 64 + xlx * 16;
-    const __amdgpu_buffer_rsrc_t rs = rsrc_of(xb);
-    char* xs = smem + buf * Cfg::XBUF + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < NXL; ++i) {
-      int pk = pp[i];
-      asm volatile("" : "+v"(pk));
-      const int voff = pk < 0 ? -1 : pk * ldb + cofs;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(xs + i * (NT * 16)), 16, voff, 0, 0, 0);
-    }
-  };
-  auto issue_w = [&](int cc, int tap, int slot) {
-    const int so = (wtile0 + tap * Ctot + cc * BKE) * (int)sizeof(T);
-    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(a.W);
-#pragma unroll
-    for (int i = 0; i < WLD; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, wvoff,
-                                               so + i * 64 * a.Ktot * (int)sizeof(T), 0, 0);
-  };
-  int w2tile = 0;                                    // N tile of the side-source weights (= the tile's tile_n)
-  auto issue_w2 = [&](int e, int slot) {
-    int tt = t;
-    asm volatile("" : "+v"(tt));
-#pragma unroll
-    for (int i = 0; i < WLD; ++i) {
-      const int row = (i * NT + tt) >> 2;
-      const T* wp = reinterpret_cast<const T*>(a.W2) + (size_t)(w2tile * 128 + epi_wrow(row, false)) * a.C2 + ((tt & 3) ^ swz64(row)) * EPC + e * BKE;
-      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wp),
-                                       (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, 0, 0);
-    }
-  };
-
-  // ---- fragment read addresses (tile independent) ----
-  const int xl = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64 + lq * 16;
-  int joff[TM];
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int p = wm * 128 + j * 16;
-    const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
-    joff[j] = __builtin_amdgcn_readfirstlane((py * g.hw + px) * 64);
-  }
-  const int woff0 = lds64_off(wn * 64 + lr, lq);
-
-  f32x4 acc[TN][TM];
-  auto mma_tap = [&](const char* Wst, const char* Xb, int tapoff) {
-    chunk16 wf[TN];
-#pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff0 + i * 1024);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      chunk16 xf[TM / 2];
-#pragma unroll
-      for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[h * (TM / 2) + j]) + xl);
-#pragma unroll
-      for (int j = 0; j < TM / 2; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) acc[i][h * (TM / 2) + j] = Mma<T>::run(wf[i], xf[j], acc[i][h * (TM / 2) + j]);
-      if (h == 0) __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  constexpr int FLY = (PD - 1) * WLD;
-  int tile = blockIdx.x;
-  TileD cur = decode(tile);
-  setup_tile(cur);
-  int gch = 0, gst = 0;                              // running X-chunk / W-step counters: buffer parity and ring slot continue across tiles
-  issue_x(0, 0);
-#pragma unroll
-  for (int i = 0; i < PD; ++i) issue_w(0, i, i);
-  bool fresh = false;                                // true: this tile's first loads were prefetched and are known to have landed
-  for (;;) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    w2tile = cur.tile_n;
-    const int pa = cur.phase >> 1, pb = cur.phase & 1;
-    for (int cc = 0; cc < nchunks; ++cc) {
-      const bool side_next = cc + 1 == nchunks && nx > 0;
-      const bool has_next = cc + 1 < nchunks || side_next;
-      const bool known = fresh && cc == 0;           // taps 0 .. PD-1: W(0 .. PD-1) and X(0) landed before the previous epilogue's stores
-      const char* Xb = smem + (gch & 1) * Cfg::XBUF;
-      auto step = [&](auto tapc) {
-        constexpr int tap = decltype(tapc)::value;
-        if (!(known && tap < PD)) {
-          if (has_next) {
-            if (tap >= 1 && tap <= PD) hwait_vmcnt<FLY + NXL>();
-            else hwait_vmcnt<FLY>();
-          } else {
-            constexpr int left = NTAP - 1 - tap;
-            hwait_vmcnt<(left < PD - 1 ? left : PD - 1) * WLD>();
-          }
-        }
-        __builtin_amdgcn_s_barrier();
-        constexpr int t2 = tap + PD;
-        if (t2 < NTAP) issue_w(cc, t2, (gst + t2) % WR);
-        else if (side_next) { if (t2 - NTAP < nx) issue_w2(t2 - NTAP, (gst + t2) % WR); }
-        else if (has_next) issue_w(cc + 1, t2 - NTAP, (gst + t2) % WR);
-        if (tap == 0 && has_next) issue_x(cc + 1, (gch + 1) & 1);
-        const char* Wst = Wring + ((gst + tap) % WR) * HALO_WST;
-        constexpr int ky = UP4 ? (tap >> 1) : tap / 3, kx = UP4 ? (tap & 1) : tap - ky * 3;
-        const int tapoff = ((ky + pa) * g.hw + kx + pb) * 64;
-        mma_tap(Wst, Xb, tapoff);
-      };
-      step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
-      if constexpr (NTAP == 9) { step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{}); }
-      gst += NTAP;
-      ++gch;
-    }
-    for (int e = 0; e < nx; ++e) {                   // 1x1 side source: one centre tap per 32-channel chunk
-      if (e == 0 && nx >= PD) hwait_vmcnt<FLY>();
-      else hwait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (e + PD < nx) issue_w2(e + PD, (gst + PD) % WR);
-      if (e + 1 < nx) issue_x(nchunks + e + 1, (gch + 1) & 1);
-      const char* Xb = smem + (gch & 1) * Cfg::XBUF;
-      const char* Wst = Wring + (gst % WR) * HALO_WST;
-      mma_tap(Wst, Xb, (g.hw + 1) * 64);
-      ++gst;
-      ++gch;
-    }
-
-    // ---- next tile's first loads, issued under this tile's epilogue.  LDS: every wave has passed the barrier of the last
-    // step, so X buffer gch & 1 (last read one chunk ago) and W slots gst .. gst+PD-1 (mod WR: all but the last step's slot,
-    // which other waves may still be reading) are free.  pp / bases / wtile0 now describe the NEXT tile; the epilogue below
-    // only uses `cur`. ----
-    const int nxt = tile + (int)gridDim.x;
-    const bool more = nxt < ntiles;
-    TileD nd = cur;
-    if (more) {
-      nd = decode(nxt);
-      setup_tile(nd);
-      issue_x(0, gch & 1);
-#pragma unroll
-      for (int i = 0; i < PD; ++i) issue_w(0, i, (gst + i) % WR);
-    }
-
-    // ---- epilogue of `cur` (igemm_epilogue.h).  It drains this wave's LDS-DMA (vmcnt 0) behind its own loads and before
-    // its first store, so the prefetched groups are known to be in when the next tile starts. ----
-    {
-      const int ng = cur.ng, ty = cur.ty, tx = cur.tx;
-      const int nw0 = min(ng, g.n_img - 1);
-      HaloQs qsfn;
-      qsfn.nbase = ng; qsfn.ltp = g.ltw + g.lth; qsfn.n_img = g.n_img; qsfn.tile_in_img = ty * g.tiles_x + tx; qsfn.wm = wm;
-      qsfn.np = HW >= 128 ? HW >> 7 : 1;
-      qsfn.padd = 0;
-      if (UP4) { qsfn.padd = cur.phase * qsfn.np; qsfn.np *= 4; }
-      epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, cur.tile_n, wn, lq, nw0, nw0, [&](int j, EpiRow& r) {
-        const int p = wm * 128 + j * 16 + lr;
-        const int n = ng;                              // one image per patch
-        r.ok = n < g.n_img;
-        const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
-        const int rem = (ty * th + py) * g.W + tx * tw + px;
-        r.samp = n;
-        r.o = UP4 ? n * (4 * HW) + (2 * (ty * th + py) + pa) * (2 * g.W) + 2 * (tx * tw + px) + pb : n * HW + rem;
-        r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
-      }, [&]() { hwait_vmcnt<0>(); }, qsfn);
-    }
-    if (!more) break;
-    tile = nxt;
-    cur = nd;
-    fresh = true;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Thin-output variant (Cout <= 16: the UNets' conv_out, 3-12 channels): same 256-pixel halo patch and X loader, but ONE
 // 16-cout MFMA fragment; the four waves split the patch (64 pixels each).  The layer reads ~1 GB of activations for 3
 // output channels: it is bound by that read, and the tap-gather kernel it replaces (igemm_kernel<128x32>) re-read every
@@ -923,28 +675,7 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
   if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 1> : conv3_halo_kernel<T, NW, false, 9, 1>;
   if constexpr (NW == 8) { if (g.mos) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 2> : conv3_halo_kernel<T, NW, false, 9, 2>; }
-  long long grid = nblk;
-  static const bool no_pers = getenv("DCAMD_HALO_NO_PERSIST") != nullptr;
-  if (g.xbuf && !no_pers) {
-    // persistent form: one workgroup per resident slot (2 per CU for the 4-wave patch, 1 for the 8-wave one), each walking
-    // tiles bid, bid + grid, ...; the slot count is a multiple of 8, which keeps tile & 7 = the workgroup's XCD
-    static int n_cu = 0;
-    static bool pers_attr[2] = {false, false};
-    if (!n_cu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-      if (n_cu <= 0) n_cu = 256;
-    }
-    kern = up4 ? conv3_halo_pers_kernel<T, NW, 4> : conv3_halo_pers_kernel<T, NW, 9>;
-    if (!pers_attr[up4 ? 1 : 0]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-      pers_attr[up4 ? 1 : 0] = true;
-    }
-    const long long slots = (long long)(n_cu & ~7) * (NW == 4 ? 2 : 1);
-    if (grid > slots) grid = slots;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS, s, a, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
 }
 

@@ -19,7 +19,7 @@ def family(kernel):
     k = kernel.replace(" ", "")
     dt = "bf16" if ("DF16b" in k or "__bf16" in k) else ("f16" if ("DF16_" in k or "_Float16" in k) else "f32")
     ints = [int(v.replace("n", "-")) for v in re.findall(r"Li(n?\d+)E", k)] or [int(v) for v in re.findall(r"[<,](-?\d+)(?=[,>])", k)]
-    if "conv3_halo_kernel" in k:
+    if "conv3_halo_kernel" in k or "conv3_halo_pers_kernel" in k:     # <T, NW, (GN,) NTAP, ...>: the persistent form is the same family
         if len(ints) > 1 and ints[1] == 4:                      # NTAP = 4: the four-phase upsample conv
             return f"conv3_up4<{dt},{ints[0]}w>"
         return f"conv3_halo<{dt},{ints[0]}w>"
