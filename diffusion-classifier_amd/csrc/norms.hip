@@ -455,7 +455,12 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
       return dc_check_launch("dc_groupnorm(wave)");
     }
   }
-  if (!no_image && img_bytes <= img_cap && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
+  // With the producer's statistics the normalise sweep needs no reduction across a sample, so a big sample is better spread
+  // over many workgroups (gn_qfold_kernel + gn_apply_kernel, HW/256 splits) than streamed by ONE: the CheXpert / IPMSA plans
+  // put only a few hundred 1-4 MiB samples into a launch (cfg3: 4.3 -> 5.x TB/s).  The threshold is a function of (HW, C) only.
+  static const size_t qsplit_min = getenv("DCAMD_GN_QSPLIT_MIN") ? (size_t)atoll(getenv("DCAMD_GN_QSPLIT_MIN")) : (1u << 20);
+  const bool qsplit = p->qstats != nullptr && img_bytes >= qsplit_min;
+  if (!no_image && !qsplit && img_bytes <= img_cap && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
     a.qstats = p->qstats; a.qparts = p->qparts;
     int tpr = 1; while (tpr < CP) tpr <<= 1;
     const size_t lds_img = (size_t)2 * (512 / tpr) * C * sizeof(float);
