@@ -53,9 +53,8 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 // list.  Large weight matrices: M fastest inside one N panel, so blocks sharing an L2 stream the same weight
 // panel.  Small ones (<= 2 MiB, resident in every L2): N fastest, so the activation tile is fetched from HBM
 // once instead of once per N tile (the 16-tile GEGLU projection showed 4x the algorithmic FETCH_SIZE).
-// (bid of nblk: the block's own id in an ordinary launch; a persistent kernel walks bid = blockIdx.x + k * gridDim.x with
-//  gridDim.x a multiple of 8, which keeps bid & 7 = the block's XCD)
-__device__ __forceinline__ void tile_of_index(const IgemmArgs& a, int bid, int nblk, int& tile_m, int& tile_n) {
+__device__ __forceinline__ void tile_of_block(const IgemmArgs& a, int& tile_m, int& tile_n) {
+  const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   if (a.n_fast) {
@@ -65,9 +64,6 @@ __device__ __forceinline__ void tile_of_index(const IgemmArgs& a, int bid, int n
     tile_n = lid / a.tiles_m;
     tile_m = lid - tile_n * a.tiles_m;
   }
-}
-__device__ __forceinline__ void tile_of_block(const IgemmArgs& a, int& tile_m, int& tile_n) {
-  tile_of_index(a, (int)blockIdx.x, (int)gridDim.x, tile_m, tile_n);
 }
 
 // Epilogue of one wave: acc[i][j] is the 16x16 tile (cout block i, pixel block j); the lane holds 4

@@ -296,167 +296,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Persistent form of the 256 x 256 tile (1-tap GEMMs; one 512-thread workgroup per CU, so nothing overlaps a tile's
-// 128 KiB of output stores or the first K-step's fetch: at K <= 1024 they cost as much as the MFMA loop — DiT-B/4's K = 768
-// projections ran at 0.75 PF, the UNets' K = 256 .. 512 projections at 3.5 - 4.4 TB/s of the HBM they are bound by).
-// A workgroup walks tiles blockIdx.x, + gridDim.x, ...: after the last K-step of tile i it rebuilds its loader rows for tile
-// i+1 and issues that tile's first K-step into the free LDS stage, THEN runs tile i's epilogue — the fetch latency hides
-// under the epilogue, the epilogue's stores drain under tile i+1's first K-steps.  The stage parity follows a running step
-// counter.  vmcnt is one in-order counter, so the first wait after an epilogue also waits for its stores: by then they have
-// had a whole K-step of MFMAs to complete.
-template <typename T, int EV>
-__global__ __launch_bounds__(512, 2) void igemm_wide_pers_kernel(const IgemmArgs a) {
-  constexpr int EPC = Elem<T>::EPC;
-  constexpr int BKE = 8 * EPC;
-  constexpr int BM = 256, BN = 256, NT = 512, S = 2;
-  constexpr int RPI = NT / 8;                // 64 tile rows per LDS-DMA instruction of the workgroup
-  constexpr int WL = BN / RPI;               // 4 W loads per lane per K-step (X: BM / RPI == 4)
-  constexpr int XST = BM * 128, STAGE = (BM + BN) * 128;
-  constexpr int TM = 4, TN = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int HWo = a.Hout * a.Wout;
-  const int lrow = t >> 3;
-  const int lchunk = (t & 7) ^ ((t >> 4) & 7);
-  const int ntiles = a.tiles_m * a.tiles_n;  // a.tiles_n counts 256-cout tiles here (launch_wide_pers)
-  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (t & 7) * 16;
-
-  // ---- per-tile loader state: one row pointer per source and loader row, the weight panel of the N tile ----
-  const T* xrow0[4]; const T* xrow1[4];
-  const T* wbase = nullptr;
-  int wro[WL];
-#pragma unroll
-  for (int i = 0; i < WL; ++i) {
-    const int R = lrow + RPI * i;
-    wro[i] = ((R >> 7) * 128 + epi_wrow(R & 127, a.act == DC_ACT_GEGLU)) * a.Ktot;
-  }
-  auto setup_tile = [&](int tile_m, int tile_n) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = tile_m * BM + lrow + RPI * i;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int n = mm / HWo;
-      const int rem = mm - n * HWo;
-      const int n0 = a.map0 ? a.map0[n] : n;
-      const int n1 = a.src1 ? (a.map1 ? a.map1[n] : n) : 0;
-      xrow0[i] = vm ? reinterpret_cast<const T*>(a.src0) + ((size_t)n0 * HWo + rem) * a.ld0 + lchunk * EPC : nullptr;
-      xrow1[i] = (vm && a.src1) ? reinterpret_cast<const T*>(a.src1) + ((size_t)n1 * HWo + rem) * a.ld1 + lchunk * EPC : nullptr;
-      // consume the map loads now: an ordinary load still pending inside the loop would make hipcc drain the LDS-DMA queue
-      asm volatile("" ::"v"(xrow0[i]), "v"(xrow1[i]));
-    }
-    wbase = reinterpret_cast<const T*>(a.W) + (size_t)(tile_n * BN) * a.Ktot + lchunk * EPC;
-  };
-  auto issue = [&](int ks, int st) {          // K-step ks of the current tile into LDS stage st
-    const bool s1 = ks >= a.c0chunks;
-    const int coff = (s1 ? ks - a.c0chunks : ks) * BKE;
-    char* xs = smem + st * STAGE + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const T* rp = s1 ? xrow1[i] : xrow0[i];
-      const char* gp = rp ? reinterpret_cast<const char*>(rp + coff) : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
-    }
-    char* ws = smem + st * STAGE + XST + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < WL; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wbase + wro[i] + ks * BKE), (lptr_t)(ws + i * (NT * 16)), 16, 0, 0);
-  };
-
-  const int wrow0 = wn * 128;
-  int wfo[2], xfo[2];
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    wfo[sub] = XST + lds_off(wrow0 + lr, sub * 4 + lq);
-    xfo[sub] = lds_off(wm * 64 + lr, sub * 4 + lq);
-  }
-
-  int tile = blockIdx.x, tile_m, tile_n;
-  tile_of_index(a, tile, ntiles, tile_m, tile_n);
-  setup_tile(tile_m, tile_n);
-  int gks = 0;                               // running K-step counter: stage = gks & 1
-  issue(0, 0);
-  bool fresh = false;
-  f32x4 acc[2][TN][TM];
-  for (;;) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < a.nk; ++ks) {
-      if (!(fresh && ks == 0)) wait_vmcnt<0>();   // a prefetched first step landed before the previous epilogue's stores were issued
-      __builtin_amdgcn_s_barrier();
-      if (ks + 1 < a.nk) issue(ks + 1, (gks + 1) & 1);
-      const char* Xs = smem + (gks & 1) * STAGE;
-      const uint32_t stb = lds_addr_of(Xs);
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const uint32_t wa = stb + wfo[sub], xa = stb + xfo[sub];
-        chunk16 xf[TM], wf[TN];
-        lgkm_fence0();
-        wf[0] = ds_read16_async_off<0>(wa); wf[1] = ds_read16_async_off<2048>(wa);
-        wf[2] = ds_read16_async_off<4096>(wa); wf[3] = ds_read16_async_off<6144>(wa);
-        xf[0] = ds_read16_async_off<0>(xa); xf[1] = ds_read16_async_off<2048>(xa);
-        xf[2] = ds_read16_async_off<4096>(xa); xf[3] = ds_read16_async_off<6144>(xa);
-#define WP_MMA(H, J, NLEFT)                                                            \
-        lgkm_wait<NLEFT>(xf[J]);                                                          \
-        _Pragma("unroll") for (int i = 0; i < TN; ++i) acc[H][i][J] = Mma<T>::run(wf[i], xf[J], acc[H][i][J]);  \
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm_wait<3>(wf[0], wf[1], wf[2], wf[3], xf[0]);
-        WP_MMA(0, 0, 3) WP_MMA(0, 1, 2) WP_MMA(0, 2, 1) WP_MMA(0, 3, 0)
-        wf[0] = ds_read16_async_off<8192>(wa); wf[1] = ds_read16_async_off<10240>(wa);
-        wf[2] = ds_read16_async_off<12288>(wa); wf[3] = ds_read16_async_off<14336>(wa);
-        lgkm_wait<0>(wf[0], wf[1], wf[2], wf[3], xf[0]);
-        WP_MMA(1, 0, 0) WP_MMA(1, 1, 0) WP_MMA(1, 2, 0) WP_MMA(1, 3, 0)
-#undef WP_MMA
-      }
-      ++gks;
-    }
-    // ---- next tile's loader rows and first K-step (LDS stage gks & 1 was last read two steps ago; every wave has passed
-    // the barrier of the last step since) ----
-    const int nxt = tile + (int)gridDim.x;
-    const bool more = nxt < ntiles;
-    int ntm = tile_m, ntn = tile_n;
-    if (more) {
-      tile_of_index(a, nxt, ntiles, ntm, ntn);
-      setup_tile(ntm, ntn);
-      issue(0, gks & 1);
-    }
-    // ---- epilogue of (tile_m, tile_n): straight from the accumulators (igemm_epilogue.h) ----
-    {
-      const int mw0 = tile_m * BM + wm * 64;
-      const int ctm = tile_m;
-      auto rowfn = [&](int j, EpiRow& r) {
-        const int m = ctm * BM + wm * 64 + j * 16 + lr;
-        r.ok = m < a.M;
-        const int mm = r.ok ? m : a.M - 1;
-        const int n = mm / HWo;
-        r.samp = n;
-        r.o = mm;
-        r.r = (a.residual && a.res_map) ? a.res_map[n] * HWo + (mm - n * HWo) : mm;
-      };
-      const int sf = min(mw0, a.M - 1) / HWo, sl = min(mw0 + 63, a.M - 1) / HWo;
-      constexpr int ACT = EV == 3 ? DC_ACT_GELU_TANH : (EV == 2 ? DC_ACT_GEGLU : DC_ACT_NONE);
-      // the first half's epilogue drains this wave's LDS-DMA (vmcnt 0) before its first store: the prefetched K-step is then
-      // known to be in when the next tile starts (an epilogue without bias / residual issues no load of its own to wait for)
-      epi_direct_act<T, TM, ACT, EV == 4, false>(a, acc[0], tile_n * 2 + wn, 0, lq, sf, sl, rowfn, [&]() { wait_vmcnt<0>(); });
-      __builtin_amdgcn_sched_barrier(0);
-      epi_direct_act<T, TM, ACT, EV == 4, false>(a, acc[1], tile_n * 2 + wn, 1, lq, sf, sl, rowfn);
-    }
-    if (!more) break;
-    tile = nxt; tile_m = ntm; tile_n = ntn;
-    fresh = true;
-  }
-}
-
 template <typename T, int BM, int S, int NH, int EV, bool SLIM>
 static int launch_pipe(const IgemmArgs& a0, hipStream_t s) {
   constexpr int lds = S * (BM + 128 * NH) * 128;                   // 144 KiB (256x128, S 3) / 64 KiB (128x128, S 2) / 128 KiB (256x256, S 2)
@@ -475,40 +314,8 @@ static int launch_pipe(const IgemmArgs& a0, hipStream_t s) {
   return dc_check_launch("dc_igemm(pipe)");
 }
 
-template <typename T, int EV>
-static int launch_wide_pers_ev(const IgemmArgs& a0, hipStream_t s) {
-  constexpr int lds = 2 * 512 * 128;
-  static bool attr_done = false;
-  static int n_cu = 0;
-  auto kern = igemm_wide_pers_kernel<T, EV>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    attr_done = true;
-  }
-  IgemmArgs a = a0;
-  a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = a0.tiles_n / 2;                                      // a0.tiles_n counts 128-cout tiles
-  const long long nblk = (long long)a.tiles_m * a.tiles_n;
-  if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("dc_igemm: bad grid %lld", nblk); return DC_ERR_SHAPE; }
-  // one workgroup per CU (128 KiB of LDS), a multiple of 8 so that tile & 7 stays the workgroup's XCD
-  const long long slots = n_cu & ~7;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nblk < slots ? nblk : slots)), dim3(512), lds, s, a);
-  return dc_check_launch("dc_igemm(wide, persistent)");
-}
-
 template <typename T>
 static int launch_wide(const IgemmArgs& a, hipStream_t s) {
-  static const bool no_pers = getenv("DCAMD_PIPE_NO_PERSIST") != nullptr;
-  if (!no_pers) {
-    if (a.act == DC_ACT_GELU_TANH) return launch_wide_pers_ev<T, 3>(a, s);
-    if (a.act == DC_ACT_GEGLU) return launch_wide_pers_ev<T, 2>(a, s);
-    if (a.gate) return launch_wide_pers_ev<T, 4>(a, s);
-    return launch_wide_pers_ev<T, 0>(a, s);
-  }
   if (a.act == DC_ACT_GELU_TANH) return launch_pipe<T, 256, 2, 2, 3, true>(a, s);
   if (a.act == DC_ACT_GEGLU) return launch_pipe<T, 256, 2, 2, 2, true>(a, s);
   if (a.gate) return launch_pipe<T, 256, 2, 2, 4, true>(a, s);
