@@ -50,6 +50,13 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 // fragments: all loads, then the final fp32 values are formed IN PLACE in the accumulators; (B) only after the last
 // batch: conversions and stores, nothing left to wait for.
 struct EpiNoPre { __device__ __forceinline__ void operator()() const {} };
+// bias values fetched by the caller ahead of time (igemm_xreg: the loads of an N tile's bias are issued before its K loop, so
+// their latency sits under the MFMAs instead of in front of the epilogue).  BiasFn::on selects the code; biasfn(k, bs, bgt)
+// fills run k's 8 bias values (and, GEGLU, the 8 gate-row values).
+struct EpiNoBias {
+  static constexpr bool on = false;
+  __device__ __forceinline__ void operator()(int, float (&)[8], float (&)[8]) const {}
+};
 
 // quad statistics for a following GroupNorm (IgemmArgs::qstats).  QsFn::on selects the code; qsfn(half, n, part):
 // the output sample and part index of pixel fragments [4 half, 4 half + 4) of the wave (wave-uniform), false when that
@@ -61,9 +68,11 @@ struct EpiNoQs {
   __device__ __forceinline__ int parts() const { return 1; }
 };
 
-template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn, typename PreFn = EpiNoPre, typename QsFn = EpiNoQs>
+template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn, typename PreFn = EpiNoPre, typename QsFn = EpiNoQs,
+          typename BiasFn = EpiNoBias>
 __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[4][TM], int tile_n, int wn, int lq,
-                                               int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn(), QsFn qsfn = QsFn()) {
+                                               int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn(), QsFn qsfn = QsFn(),
+                                               BiasFn biasfn = BiasFn()) {
   constexpr bool geglu = ACT == DC_ACT_GEGLU;
   constexpr int NK = geglu ? 1 : 2;                  // 8-channel runs per pixel
   constexpr int JB = TM;                             // pixel fragments per load batch: all of them — one exposed residual latency per tile
@@ -83,7 +92,9 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
       const int c = c0 + 32 * k;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { bs[k][e] = 0.f; if (k == 0) bgt[e] = 0.f; }
-      if (a.bias && con[k]) {
+      if constexpr (BiasFn::on) {
+        biasfn(k, bs[k], bgt);
+      } else if (a.bias && con[k]) {
         const int p = geglu ? (c >> 4) * 32 + (c & 15) : c;
         ld8(a.bias + p, bs[k]);
         if (geglu) ld8(a.bias + p + 16, bgt);

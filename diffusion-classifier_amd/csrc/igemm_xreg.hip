@@ -30,6 +30,16 @@ constexpr int XR_SLICE = 128 * 128;  // bytes per slice: 128 couts x 64 k x 2 B
 constexpr int XR_WL = 4;             // LDS-DMA instructions per lane per slice (256 lanes x 16 B x 4 = 16 KiB)
 }
 
+// bias values of an N tile held in registers since before its K loop (igemm_epilogue.h BiasFn)
+struct XrPreBias {
+  static constexpr bool on = true;
+  const float (&v)[8]; const float (&g)[8];
+  __device__ __forceinline__ void operator()(int, float (&bs)[8], float (&bgt)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs[e] = v[e]; bgt[e] = g[e]; }
+  }
+};
+
 template <int N> static __device__ __forceinline__ void xr_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // GEGLU: one kernel per epilogue variant — the activations are live across the epilogue, and two variants inside one
@@ -145,6 +155,21 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
 
   int q = 0;
   for (int nt = 0; nt < a.tiles_n; ++nt) {
+    // GEGLU: this N tile's bias (8 value-row and 8 gate-row entries per lane) is fetched HERE, ahead of the K loop: the epilogue
+    // of the short-K projection ran once per 96 MFMAs and paid a global-load latency in front of its VALU work every time.
+    // (These loads are older than every weight slice issued below, so the counted vmcnt waits of the loop still mean what
+    //  they say: vmcnt is in order.)
+    float pbv[8], pbg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pbv[e] = 0.f; pbg[e] = 0.f; }
+    if (GEGLU && a.bias) {
+      const int c = nt * 64 + wn * 32 + lq * 8;
+      if (c < (a.Cout >> 1)) {
+        const int p = (c >> 4) * 32 + (c & 15);
+        ld8(a.bias + p, pbv);
+        ld8(a.bias + p + 16, pbg);
+      }
+    }
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -192,10 +217,15 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
     // SiLU / tanh-GELU / gated outputs stay on igemm_pipe.hip
     // the epilogue drains my own LDS-DMA (vmcnt 0) right after issuing its bias / row-vector loads and before its stores
     // join the counter: the next iq - q slices are then known to be in
-    epi_direct_act<T, TM, GEGLU ? DC_ACT_GEGLU : DC_ACT_NONE, false, true>(a, acc, nt, wn, lq, sf, sl_, rowfn, [&]() {
+    auto drain = [&]() {
       xr_wait_vmcnt<0>();
       landed = iq;
-    });
+    };
+    if constexpr (GEGLU) {
+      epi_direct_act<T, TM, DC_ACT_GEGLU, false, true>(a, acc, nt, wn, lq, sf, sl_, rowfn, drain, EpiNoQs(), XrPreBias{pbv, pbg});
+    } else {
+      epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, nt, wn, lq, sf, sl_, rowfn, drain);
+    }
   }
 }
 
