@@ -494,6 +494,9 @@ class _HipRunner:
         plan.run_ctx()                                   # per-class vectors: once per stage, not per micro-batch
         n_mb = -(-len(pairs) // n_bj)
         host = sp.get("host")                            # pinned staging, reused across calls (pin_memory() is slow)
+        ev = sp.get("host_ev")
+        if ev is not None:
+            ev.synchronize()                             # the previous call's asynchronous control-block copies have left `host`
         if host is None or host.shape[0] < n_mb:
             host = sp["host"] = torch.zeros((n_mb, sp["words"]), dtype=torch.int32).pin_memory()
         dump = BS * ncls * T
@@ -568,4 +571,9 @@ class _HipRunner:
                 dc._timed_sink.append((plan, plan.pb.run_timed()))
             else:
                 plan.run()
-        torch.cuda.current_stream().synchronize()    # `host` (pinned) must outlive the async copies
+        # `host` (pinned) must outlive the asynchronous copies: instead of draining the stream here (the GPU then idles while the
+        # host prepares the next call) an event marks the last copy, and the next user of the buffer waits for it — by then it has
+        # long fired, and the host side of call i+1 runs under the kernels of call i
+        if ev is None:
+            ev = sp["host_ev"] = torch.cuda.Event()
+        ev.record()
