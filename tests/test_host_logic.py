@@ -3,6 +3,7 @@ and the no-fallback rule.  No compute call touches the HIP kernels here."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -139,3 +140,27 @@ def test_geglu_perm_and_weight_packing():
     w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
     m = w.permute(0, 2, 3, 1).reshape(2, 27)
     assert m[1, 5 * 3 + 2] == w[1, 2, 1, 2]        # k = (ky*3+kx)*Cin + c
+
+
+def test_bench_starts_its_own_ranks_as_a_child_process(monkeypatch):
+    """`python bench.py --gpus N` typed by hand (no WORLD_SIZE): the parent must start torch.distributed.run as a CHILD process
+    (never exec: a process that has touched the GPU must not replace itself) on 127.0.0.1 and relay its exit code."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and os.path.basename(cmd[-5]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
