@@ -96,6 +96,18 @@ struct HaloQs {
   }
 };
 
+// bias (+ per-sample row vector) of the workgroup's N tile staged in LDS at kernel start (igemm_epilogue.h BiasFn): run k of the
+// lane starts 32 k channels after p
+struct HaloLdsBias {
+  static constexpr bool on = true, has_rowvec = true;
+  const float* p;
+  __device__ __forceinline__ void operator()(int k, float (&bs)[8], float (&)[8]) const {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p + 32 * k), hi = *reinterpret_cast<const f32x4*>(p + 32 * k + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bs[e] = lo[e]; bs[4 + e] = hi[e]; }
+  }
+};
+
 template <int N> __device__ __forceinline__ void hwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -177,6 +189,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
         pp[i] = (img << 20) | (a.upsample ? (iy >> 1) * (g.W >> 1) + (ix >> 1) : iy * g.W + ix);
       }
     }
+  }
+  // XB (one image per patch = one sample per workgroup): bias + the sample's row vector of this N tile, summed once into LDS (the
+  // GroupNorm slot, unused here) while the piece offsets are being formed — the epilogue then reads them at LDS latency instead of
+  // paying a global-load round trip (~2.5 k of a ~19 k-cycle epilogue by s_memtime stamps) in front of its first use.
+  float* const brv = reinterpret_cast<float*>(smem + Cfg::GNOFF);
+  constexpr bool STAGE_BRV = XB && !GN;
+  if (STAGE_BRV && t < 128) {
+    const int c = tile_n * 128 + t;
+    float v = 0.f;
+    if (c < a.Cout) {
+      if (a.bias) v = a.bias[c];
+      if (a.rowvec) v += a.rowvec[(size_t)(a.rowvec_map ? a.rowvec_map[ng] : ng) * a.rowvec_ld + c];
+    }
+    brv[t] = v;
   }
   __syncthreads();
   const char* zero = reinterpret_cast<const char*>(g_zero_page);      // wave-uniform (any 16 zero bytes do)
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   qsfn.np = HW >= 128 ? HW >> 7 : 1;
   qsfn.padd = 0;
   if (UP4) { qsfn.padd = phase * qsfn.np; qsfn.np *= 4; }       // every phase contributes its own parts of the output sample
-  epi_direct_act<T, TM, DC_ACT_NONE, false, !MOS>(a, acc, tile_n, wn, lq, nw0, nw1, [&](int j, EpiRow& r) {
+  auto rowfn = [&](int j, EpiRow& r) {
     const int p = wm * 128 + j * 16 + lr;
     int n = (ng << g.lni) + (p >> (g.ltw + g.lth));
     r.ok = n < g.n_img;
@@ -443,7 +469,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     r.samp = n;
     r.o = UP4 ? n * (4 * HW) + (2 * (ty * th + py) + pa) * (2 * g.W) + 2 * (tx * tw + px) + pb : n * HW + rem;
     r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
-  }, EpiNoPre(), qsfn);
+  };
+  if constexpr (STAGE_BRV) {
+    epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, rowfn, EpiNoPre(), qsfn, HaloLdsBias{brv + wn * 64 + lq * 8});
+  } else {
+    epi_direct_act<T, TM, DC_ACT_NONE, false, !MOS>(a, acc, tile_n, wn, lq, nw0, nw1, rowfn, EpiNoPre(), qsfn);
+  }
   DC_STAMP(7);
 }
 

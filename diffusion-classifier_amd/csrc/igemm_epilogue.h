@@ -52,9 +52,10 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 struct EpiNoPre { __device__ __forceinline__ void operator()() const {} };
 // bias values fetched by the caller ahead of time (igemm_xreg: the loads of an N tile's bias are issued before its K loop, so
 // their latency sits under the MFMAs instead of in front of the epilogue).  BiasFn::on selects the code; biasfn(k, bs, bgt)
-// fills run k's 8 bias values (and, GEGLU, the 8 gate-row values).
+// fills run k's 8 bias values (and, GEGLU, the 8 gate-row values).  has_rowvec: the values already include the per-sample row
+// vector (conv3_halo stages bias + row vector of its sample in LDS at kernel start), so the epilogue fetches neither.
 struct EpiNoBias {
-  static constexpr bool on = false;
+  static constexpr bool on = false, has_rowvec = false;
   __device__ __forceinline__ void operator()(int, float (&)[8], float (&)[8]) const {}
 };
 
@@ -104,7 +105,7 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     // a wave's pixels normally lie inside one image)
     const bool uni = samp_first == samp_last;
     prefn();      // the caller's own waits (igemm_xreg drains its LDS-DMA here) overlap the bias loads issued above
-    if (!geglu && a.rowvec && uni) {
+    if (!BiasFn::has_rowvec && !geglu && a.rowvec && uni) {
 #pragma unroll
       for (int k = 0; k < NK; ++k)
         if (con[k]) {
@@ -124,7 +125,7 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
           for (int k = 0; k < NK; ++k) acc[2 * k + (e >> 2)][j][e & 3] += bs[k][e];
         }
       }
-    if (!geglu && a.rowvec && !uni) {
+    if (!BiasFn::has_rowvec && !geglu && a.rowvec && !uni) {
       if (TWO_SAMP) {
         // the wave's pixels belong to samp_first or samp_last only (images at least as large as the wave's pixel range:
         // the dispatcher guarantees it): fetch both vectors, select per lane — no per-pixel address arithmetic

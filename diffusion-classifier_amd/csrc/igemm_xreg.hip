@@ -32,7 +32,7 @@ constexpr int XR_WL = 4;             // LDS-DMA instructions per lane per slice 
 
 // bias values of an N tile held in registers since before its K loop (igemm_epilogue.h BiasFn)
 struct XrPreBias {
-  static constexpr bool on = true;
+  static constexpr bool on = true, has_rowvec = false;
   const float (&v)[8]; const float (&g)[8];
   __device__ __forceinline__ void operator()(int, float (&bs)[8], float (&bgt)[8]) const {
 #pragma unroll

@@ -8,7 +8,7 @@ out = os.path.join(ROOT, "gpurun_out", "libdcamd_stamps.so")
 src = os.path.join(ROOT, "diffusion-classifier_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDC_STAMPS", "-shared",
                 f"-I{ROOT}/include", "-o", out] + [os.path.join(src, f) for f in
-                ("igemm.hip", "igemm_pipe.hip", "igemm_xreg.hip", "conv3_halo.hip", "norms.hip", "attention.hip", "attention_mfma.hip", "elementwise.hip", "api.hip")], check=True)
+                ("igemm.hip", "igemm_pipe.hip", "igemm_xreg.hip", "conv3_halo.hip", "norms.hip", "attention.hip", "attention_mfma.hip", "elementwise.hip", "stage.hip", "pack.hip", "api.hip")], check=True)
 os.environ["DCAMD_LIB"] = out
 import torch
 import diffusion_classifier_amd as dca
