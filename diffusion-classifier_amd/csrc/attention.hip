@@ -69,6 +69,8 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs a) {
 // attention_mfma.hip: matrix-core kernel for 16-bit dtypes, L % 16 == 0, d % 32 == 0
 bool dc_attn_mfma_applicable(int dtype, int L, int d);
 int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s);
+bool dc_attn_wave_applicable(const dc_attention_params* p);  // L <= 64: one wave per (sample, head) pair
+int dc_attn_wave_launch(const dc_attention_params* p, hipStream_t s);
 bool dc_attn_flash_applicable(int dtype, int L, int d);     // long sequences (DiT), online softmax
 int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s);
 
@@ -79,6 +81,7 @@ extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   DC_REQUIRE(p->ld_qkv >= p->heads * p->d && p->ld_out >= p->heads * p->d, DC_ERR_SHAPE, "dc_attention: ld");
   static const bool no_mfma = getenv("DCAMD_ATTN_VALU") != nullptr;
   static const int mfma_maxl = getenv("DCAMD_ATTN_MFMA_MAXL") ? atoi(getenv("DCAMD_ATTN_MFMA_MAXL")) : 256;
+  if (!no_mfma && dc_attn_wave_applicable(p)) return dc_attn_wave_launch(p, reinterpret_cast<hipStream_t>(stream));
   if (!no_mfma && p->L <= mfma_maxl && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
   static const bool force_flash = getenv("DCAMD_ATTN_FLASH") != nullptr;
   const size_t lds = (size_t)2 * p->L * p->d * sizeof(float);

@@ -500,6 +500,161 @@ static int launch_flash_t(const FlashArgs& a, long long nb, hipStream_t s) {
   return dc_check_launch("dc_attention(flash_t)");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Token counts of the UNets' deep levels (L = 16 ... 64: 4x4 / 8x8 images): ONE WAVE per (sample, head) pair, four pairs per
+// workgroup, nothing shared between waves and therefore no workgroup barrier.  Same arithmetic as attn_flash_t_kernel with a
+// single key block: K and V of the pair are staged row-major (16-byte chunks) in a wave-private LDS strip; S^T = K Q^T
+// (D-fragment = 4 consecutive keys of one query per lane), softmax in registers on log2-scaled scores (v_exp_f32, two
+// xor-shuffles per query), the packed P^T D-fragments fed back as the B operand of O^T += V^T P^T with the A operand read by
+// ds_read_b64_tr_b16, 8-byte output stores.  The first matrix-core kernel for these shapes (attn_mfma_kernel above: V transposed
+// by 2-byte LDS writes, P through LDS, 2-byte strided output stores, one workgroup barrier) ran them at 2.5 - 2.9 TB/s of the
+// q/k/v + output bytes they are bound by.
+template <typename T, int D, int NKT>                          // NKT: 16-key tiles per pair (even; L <= 16 NKT, keys past L masked)
+__global__ __launch_bounds__(256) void attn_wave_kernel(const FlashArgs a) {
+  constexpr int LP = NKT * 16, NDT = D / 16, NKB = D / 32;
+  constexpr int PITCH = D + 8, CPR = D / 8;
+  constexpr int NCH = LP * CPR / 64;                           // staging chunks per lane and operand
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int L = a.L;
+  const long long pair = (long long)blockIdx.x * 4 + wave;
+  if (pair >= (long long)a.n * a.heads) return;               // whole waves leave: nothing below is shared between waves
+  const int n = (int)(pair / a.heads), h = (int)(pair % a.heads);
+  T* const Kl = reinterpret_cast<T*>(smem) + (size_t)wave * 2 * LP * PITCH;
+  T* const Vl = Kl + LP * PITCH;
+  const T* qg = reinterpret_cast<const T*>(a.q) + (size_t)n * L * a.ld_qkv + h * D;
+  const T* kg = reinterpret_cast<const T*>(a.k) + (size_t)n * L * a.ld_qkv + h * D;
+  const T* vg = reinterpret_cast<const T*>(a.v) + (size_t)n * L * a.ld_qkv + h * D;
+  // ---- stage K and V (rows past L as zeros: a masked key has P = 0, and 0 x garbage must not be a NaN) ----
+#pragma unroll
+  for (int i0 = 0; i0 < NCH; i0 += 8) {
+    chunk16 kc[8], vc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + u < NCH) {
+        const int idx = (i0 + u) * 64 + lane, r = idx / CPR, c = idx - r * CPR;
+        kc[u] = chunk16{0u, 0u, 0u, 0u}; vc[u] = kc[u];
+        if (r < L) {
+          kc[u] = *reinterpret_cast<const chunk16*>(kg + (size_t)r * a.ld_qkv + c * 8);
+          vc[u] = *reinterpret_cast<const chunk16*>(vg + (size_t)r * a.ld_qkv + c * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + u < NCH) {
+        const int idx = (i0 + u) * 64 + lane, r = idx / CPR, c = idx - r * CPR;
+        *reinterpret_cast<chunk16*>(Kl + r * PITCH + c * 8) = kc[u];
+        *reinterpret_cast<chunk16*>(Vl + r * PITCH + c * 8) = vc[u];
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float sc2 = a.scale * 1.4426950408889634f;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int nqt = (L + 15) >> 4;
+  for (int qt = 0; qt < nqt; ++qt) {                           // wave-uniform trip count
+    const int qi = qt * 16 + lr;
+    chunk16 qf[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      qf[kb] = *reinterpret_cast<const chunk16*>(qg + (size_t)(qi < L ? qi : L - 1) * a.ld_qkv + kb * 32 + lq * 8);
+    f32x4 S[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const chunk16 kf = *reinterpret_cast<const chunk16*>(Kl + (kt * 16 + lr) * PITCH + kb * 32 + lq * 8);
+        acc = Mma<T>::run(kf, qf[kb], acc);                   // rows = keys, column = query
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kvalid = kt * 16 + lq * 4 + r < L;
+        acc[r] = kvalid ? acc[r] * sc2 : -INFINITY;
+        mx = fmaxf(mx, acc[r]);
+      }
+      S[kt] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ps = 0.f;
+    s16x4 P[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(S[kt][r] - mx); ps += pv[r]; }
+      typename Elem<T>::vec4 pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pk[r] = Elem<T>::from_f(pv[r]);
+      P[kt] = __builtin_bit_cast(s16x4, pk);
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(ps);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kp = 0; kp < NKT / 2; ++kp) {
+        s16x4 vf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const T* vp = Vl + ((2 * kp + u) * 16 + lq * 4 + (lr >> 2)) * PITCH + dt * 16 + (lr & 3) * 4;
+          vf[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(const_cast<T*>(vp)));
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 av = __builtin_shufflevector(vf[0], vf[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x8 bv = __builtin_shufflevector(P[2 * kp], P[2 * kp + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = Mma<T>::run(__builtin_bit_cast(chunk16, av), __builtin_bit_cast(chunk16, bv), acc);   // rows = d, column = query
+      }
+      if (qi < L) {
+        typename Elem<T>::vec4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = Elem<T>::from_f(acc[r] * inv);
+        *reinterpret_cast<typename Elem<T>::vec4*>(reinterpret_cast<T*>(a.out) + ((size_t)n * L + qi) * a.ld_out + h * D + dt * 16 + lq * 4) = o;
+      }
+    }
+  }
+}
+
+template <typename T, int D, int NKT>
+static int launch_attn_wave(const FlashArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)4 * 2 * NKT * 16 * (D + 8) * 2;
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_wave_kernel<T, D, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  const long long nb = ((long long)a.n * a.heads + 3) / 4;
+  if (nb >= (1LL << 31)) { dc_set_error("dc_attention: grid too large"); return DC_ERR_SHAPE; }
+  hipLaunchKernelGGL((attn_wave_kernel<T, D, NKT>), dim3((unsigned)nb), dim3(256), lds, s, a);
+  return dc_check_launch("dc_attention(wave)");
+}
+
+// one wave per pair: 16-bit, L <= 64, d in {32, 64, 128}, 8-byte aligned output rows
+bool dc_attn_wave_applicable(const dc_attention_params* p) {
+  static const bool off = getenv("DCAMD_ATTN_NO_WAVE") != nullptr;
+  if (off || p->dtype == DC_F32 || p->L > 64 || !(p->d == 32 || p->d == 64 || p->d == 128)) return false;
+  if ((((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v) & 15) || (p->ld_qkv % 8)) return false;
+  return p->ld_out % 4 == 0 && (((uintptr_t)p->out) & 7) == 0;
+}
+
+int dc_attn_wave_launch(const dc_attention_params* p, hipStream_t s) {
+  FlashArgs a{p->q, p->k, p->v, p->out, p->n, p->L, p->heads, p->d, p->ld_qkv, p->ld_out, p->scale};
+  const bool bf = p->dtype == DC_BF16;
+  const bool two = p->L <= 32;                                 // 2 or 4 key tiles (an even count: the P.V MFMAs take key tiles in pairs)
+#define DC_AW(D) (two ? (bf ? launch_attn_wave<__bf16, D, 2>(a, s) : launch_attn_wave<_Float16, D, 2>(a, s)) \
+                      : (bf ? launch_attn_wave<__bf16, D, 4>(a, s) : launch_attn_wave<_Float16, D, 4>(a, s)))
+  if (p->d == 32) return DC_AW(32);
+  if (p->d == 64) return DC_AW(64);
+  return DC_AW(128);
+#undef DC_AW
+}
+
 bool dc_attn_flash_applicable(int dtype, int L, int d) { return dtype != DC_F32 && d % 32 == 0 && d <= 128 && L >= 1; }
 
 int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s) {

@@ -372,8 +372,9 @@ def test_layernorm_plain_and_adaln(dt, C_):
     assert (y.float().cpu() - ref).abs().max().item() < 3 * tol
 
 
-@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
-@pytest.mark.parametrize("Ld", [(64, 32), (16, 64), (256, 64), (64, 128), (100, 16), (64, 64)])
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("Ld", [(64, 32), (16, 64), (256, 64), (64, 128), (100, 16), (64, 64),
+                                (48, 32), (32, 64), (16, 128), (24, 32)])       # L <= 64: one wave per (sample, head) pair, masked key / query tiles
 def test_attention(dt, Ld):
     Lq, d = Ld
     torch.manual_seed(6)
