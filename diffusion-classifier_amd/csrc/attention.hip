@@ -80,7 +80,9 @@ extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   DC_REQUIRE(p->n > 0 && p->L > 0 && p->heads > 0, DC_ERR_SHAPE, "dc_attention: n/L/heads");
   DC_REQUIRE(p->ld_qkv >= p->heads * p->d && p->ld_out >= p->heads * p->d, DC_ERR_SHAPE, "dc_attention: ld");
   static const bool no_mfma = getenv("DCAMD_ATTN_VALU") != nullptr;
-  static const int mfma_maxl = getenv("DCAMD_ATTN_MFMA_MAXL") ? atoi(getenv("DCAMD_ATTN_MFMA_MAXL")) : 256;
+  // L <= 64: one wave per pair (attn_wave_kernel); up to 128: the whole-sequence matrix-core kernel; beyond: the flash kernel, which
+  // also wins at 256 tokens (CheXpert 16x16 level, d = 64: 2.37 -> 0.71 ms per step; IPMSA: 13.2 -> 4.8 ms)
+  static const int mfma_maxl = getenv("DCAMD_ATTN_MFMA_MAXL") ? atoi(getenv("DCAMD_ATTN_MFMA_MAXL")) : 128;
   if (!no_mfma && dc_attn_wave_applicable(p)) return dc_attn_wave_launch(p, reinterpret_cast<hipStream_t>(stream));
   if (!no_mfma && p->L <= mfma_maxl && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
   static const bool force_flash = getenv("DCAMD_ATTN_FLASH") != nullptr;

@@ -527,6 +527,16 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const FlashArgs a) {
   const T* qg = reinterpret_cast<const T*>(a.q) + (size_t)n * L * a.ld_qkv + h * D;
   const T* kg = reinterpret_cast<const T*>(a.k) + (size_t)n * L * a.ld_qkv + h * D;
   const T* vg = reinterpret_cast<const T*>(a.v) + (size_t)n * L * a.ld_qkv + h * D;
+  // ---- every query fragment of the pair up front (B operand of S^T: query lr, d = 32 kb + 8 lq .. +7): their latency then sits
+  // under the K / V staging instead of in front of each query tile ----
+  chunk16 qfa[NKT][NKB];
+#pragma unroll
+  for (int qt = 0; qt < NKT; ++qt)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int qi = qt * 16 + lr;
+      qfa[qt][kb] = *reinterpret_cast<const chunk16*>(qg + (size_t)(qi < L ? qi : L - 1) * a.ld_qkv + kb * 32 + lq * 8);
+    }
   // ---- stage K and V (rows past L as zeros: a masked key has P = 0, and 0 x garbage must not be a NaN) ----
 #pragma unroll
   for (int i0 = 0; i0 < NCH; i0 += 8) {
@@ -557,12 +567,13 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const FlashArgs a) {
   const float sc2 = a.scale * 1.4426950408889634f;
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const int nqt = (L + 15) >> 4;
-  for (int qt = 0; qt < nqt; ++qt) {                           // wave-uniform trip count
+#pragma unroll
+  for (int qt = 0; qt < NKT; ++qt) {                           // (unrolled: qfa is indexed statically; the bound is wave-uniform)
+    if (qt >= nqt) break;
     const int qi = qt * 16 + lr;
     chunk16 qf[NKB];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-      qf[kb] = *reinterpret_cast<const chunk16*>(qg + (size_t)(qi < L ? qi : L - 1) * a.ld_qkv + kb * 32 + lq * 8);
+    for (int kb = 0; kb < NKB; ++kb) qf[kb] = qfa[qt][kb];
     f32x4 S[NKT];
     float mx = -INFINITY;
 #pragma unroll
