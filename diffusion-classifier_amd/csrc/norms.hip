@@ -159,6 +159,78 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   }
 }
 
+// Normalise sweep when the statistics already exist (the producer's quad records, or one folded record per group in ws):
+// short workgroups, each streaming ONE contiguous 16 KiB span of a sample — 256 lanes x 4 chunks, every load issued before
+// the first store, non-temporal both ways.  Measured with tools/gn_stream_bench.hip on 8000 x 32x32x128 bf16 (2.1 GB in,
+// 2.1 GB out): one 512-lane workgroup looping over a whole sample (gn_image_kernel's sweep) 5.4-5.6 TB/s, a flat grid-stride
+// stream 4.6-4.9, these spans 6.4-6.5 — SiLU's VALU work and the statistics fold in front cost nothing at any of them.
+// The group statistics are folded in gn_image_kernel's order (parts outer, quads inner), so the two kernels agree bit for bit.
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void gn_span_kernel(const GnArgs a, const int spans) {
+  constexpr int EPC = Elem<T>::EPC, U = 4, RMAX = 8;             // RMAX x 256 quad records per sample at most (host check)
+  extern __shared__ __attribute__((aligned(16))) float st[];    // mean[groups], rstd[groups], then the sample's quad records
+  const int t = threadIdx.x, n = blockIdx.x / spans, sp = blockIdx.x - n * spans;
+  const int C = a.C0, CP = C / EPC;
+  const int ns = a.map0 ? a.map0[n] : n;
+  const int cpg = C / a.groups;
+  float2* const rec = reinterpret_cast<float2*>(st + 2 * a.groups);
+  // the statistics records first, every lane ONE independent load per 256 records (a lane per group walking its records one
+  // after the other made the workgroup's life a chain of L2 latencies: 16 KiB of payload behind 8-16 dependent loads)
+  const int R = a.qstats ? a.qparts * (C >> 2) : a.wsplits * a.groups;
+  const float2* const w = a.qstats ? reinterpret_cast<const float2*>(a.qstats) + (size_t)ns * R
+                                   : reinterpret_cast<const float2*>(a.ws) + (size_t)n * R;
+  float2 rv[RMAX];
+#pragma unroll
+  for (int k = 0; k < RMAX; ++k) rv[k] = (t + k * 256 < R) ? w[t + k * 256] : float2{0.f, 0.f};
+  const chunk16* src = reinterpret_cast<const chunk16*>(reinterpret_cast<const T*>(a.x0) + (size_t)ns * a.HW * C) + (size_t)sp * (256 * U) + t;
+  chunk16 c[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) c[u] = NT ? __builtin_nontemporal_load(src + u * 256) : src[u * 256];
+  const int tc = t & (CP - 1);                                   // CP is a power of two <= 256: the lane's column is the same for its U chunks
+  float gm[EPC], bt[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { gm[e] = a.gamma[tc * EPC + e]; bt[e] = a.beta[tc * EPC + e]; }
+#pragma unroll
+  for (int k = 0; k < RMAX; ++k) if (t + k * 256 < R) rec[t + k * 256] = rv[k];
+  __syncthreads();
+  for (int g = t; g < a.groups; g += 256) {
+    float S = 0.f, Q = 0.f;
+    if (a.qstats) {                                              // gn_image_kernel's order: parts outer, the group's quads inner
+      const int qpg = cpg >> 2, CQ = C >> 2;
+      for (int part = 0; part < a.qparts; ++part)
+        for (int q = 0; q < qpg; ++q) { const float2 v = rec[part * CQ + g * qpg + q]; S += v.x; Q += v.y; }
+    } else {
+      for (int k = 0; k < a.wsplits; ++k) { const float2 v = rec[k * a.groups + g]; S += v.x; Q += v.y; }
+    }
+    const float cnt = (float)cpg * (float)a.HW;
+    const float mean = S / cnt;
+    st[g] = mean;
+    st[a.groups + g] = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + a.eps);
+  }
+  __syncthreads();
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int g = (tc * EPC + e) / cpg;
+    const float r = st[a.groups + g] * gm[e];
+    sc[e] = r; sh[e] = bt[e] - st[g] * r;
+  }
+  chunk16* dst = reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.y) + (size_t)n * a.HW * C) + (size_t)sp * (256 * U) + t;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float f[EPC];
+    chunk_to_f<T>(c[u], f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float v = f[e] * sc[e] + sh[e];
+      if (a.silu) v = silu_t<T>(v);
+      f[e] = v;
+    }
+    if (NT) __builtin_nontemporal_store(f_to_chunk<T>(f), dst + u * 256);
+    else dst[u * 256] = f_to_chunk<T>(f);
+  }
+}
+
 // One workgroup per sample: statistics sweep, in-block fold, normalise sweep.  The second sweep re-reads the sample
 // while it is still on chip (L2 / Infinity Cache: all resident workgroups together hold ~256 MiB at most), so HBM sees
 // the tensor twice (read, write) instead of three times, and the summation order depends on nothing but (HW, C).
@@ -460,6 +532,32 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   // put only a few hundred 1-4 MiB samples into a launch (cfg3: 4.3 -> 5.x TB/s).  The threshold is a function of (HW, C) only.
   static const size_t qsplit_min = getenv("DCAMD_GN_QSPLIT_MIN") ? (size_t)atoll(getenv("DCAMD_GN_QSPLIT_MIN")) : (1u << 20);
   const bool qsplit = p->qstats != nullptr && img_bytes >= qsplit_min;
+  // producer statistics + a sample that divides into whole 16 KiB spans of one column set: gn_span_kernel (a function of (HW, C) only).
+  // OPT-IN (DCAMD_GN_SPAN): alone it streams 5.9-6.4 TB/s against gn_image_kernel's 5.2-5.6, and inside the scoring step GroupNorm
+  // drops from 11.1 to 10.1 ms — but the convolutions that follow slow down by the same amount (cfg2: 77.7 -> 77.9 ms per step):
+  // every kernel of the step runs at the socket's power cap (~1.37 kW, 2.08-2.18 GHz by rocm-smi), so a phase that moves the same
+  // bytes in less time only hands a hotter chip to the next phase.  DESIGN.md §6b.
+  static const bool no_span = getenv("DCAMD_GN_SPAN") == nullptr;
+  const long long chunks = (long long)p->HW * CP;
+  if (!no_span && p->qstats && C1 == 0 && CP <= 256 && (CP & (CP - 1)) == 0 && chunks % 1024 == 0 && p->groups <= 2048 &&
+      (long long)p->n * (chunks / 1024) < (1LL << 31)) {
+    a.qstats = p->qstats; a.qparts = p->qparts;
+    const bool fold = qsplit || (long long)p->qparts * (C >> 2) > 8 * 256;
+    if (fold) {                                // many quad records per sample: fold them once per sample, not once per span
+      const int CQ = C >> 2, cols = CQ < 256 ? CQ : 256;
+      hipLaunchKernelGGL(gn_qfold_kernel, dim3((unsigned)p->n), blk, (size_t)(256 / cols) * CQ * sizeof(float2), s, a);
+      a.qstats = nullptr; a.wsplits = 1;
+    }
+    const int spans = (int)(chunks / 1024);
+    const size_t lds_span = lds_apply + (size_t)(fold ? p->groups : p->qparts * (C >> 2)) * sizeof(float2);
+    dim3 gs((unsigned)((long long)p->n * spans));
+    static const bool span_nt = getenv("DCAMD_GN_SPAN_NO_NT") == nullptr;
+    if (p->dtype == DC_F32) hipLaunchKernelGGL((gn_span_kernel<float, false>), gs, blk, lds_span, s, a, spans);
+    else if (p->dtype == DC_BF16) { if (span_nt) hipLaunchKernelGGL((gn_span_kernel<__bf16, true>), gs, blk, lds_span, s, a, spans); else hipLaunchKernelGGL((gn_span_kernel<__bf16, false>), gs, blk, lds_span, s, a, spans); }
+    else if (p->dtype == DC_F16) hipLaunchKernelGGL((gn_span_kernel<_Float16, false>), gs, blk, lds_span, s, a, spans);
+    else { dc_set_error("dc_groupnorm: dtype %d", p->dtype); return DC_ERR_DTYPE; }
+    return dc_check_launch("dc_groupnorm(span)");
+  }
   if (!no_image && !qsplit && img_bytes <= img_cap && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
     a.qstats = p->qstats; a.qparts = p->qparts;
     int tpr = 1; while (tpr < CP) tpr <<= 1;

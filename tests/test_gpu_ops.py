@@ -584,6 +584,20 @@ def test_conv3x3_with_fused_groupnorm_prologue(dt, concat):
     assert lib.dc_igemm_gn_fusable(p) == 0 and lib.dc_igemm(p, L.stream_ptr()) == -6
 
 
+def test_groupnorm_span_kernel_opt_in():
+    """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
+    test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
+    import subprocess
+    import sys
+    if os.environ.get("DCAMD_GN_SPAN") is not None:
+        pytest.skip("already running with the span kernel")
+    env = dict(os.environ, DCAMD_GN_SPAN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "quad_statistics_feed_groupnorm",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
 @pytest.mark.parametrize("shape", [(3, 8, 8, 128), (5, 16, 16, 256), (3, 32, 32, 128), (2, 64, 32, 384), (3, 8, 16, 128),
                                    (2, 256, 128, 128)])       # > 4 MiB per sample: split GroupNorm, quad records folded by gn_qfold_kernel

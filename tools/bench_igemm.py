@@ -57,11 +57,29 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--cus", type=int, default=0, help="run on a stream masked to this many CUs (hipExtStreamCreateWithCUMask)")
+    ap.add_argument("--cu-pattern", default="low", choices=["low", "spread"], help="which mask bits: the low N, or N spread evenly over 256")
     args = ap.parse_args()
     dt = E.DT[args.dtype]
     td = E.TORCH_DT[dt]
     lib = L.require_gpu()
     dev = "cuda:0"
+    masked = None
+    if args.cus:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        bits = list(range(args.cus)) if args.cu_pattern == "low" else [int(i * 256 / args.cus) for i in range(args.cus)]
+        words = (ctypes.c_uint32 * 8)()
+        for b_ in bits:
+            words[b_ // 32] |= 1 << (b_ % 32)
+        sp = ctypes.c_void_p()
+        torch.zeros(1, device=dev)
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), 8, words)
+        assert rc == 0, rc
+        masked = torch.cuda.ExternalStream(sp.value)
+        print(f"# stream masked to {args.cus} CUs ({args.cu_pattern})", flush=True)
+    ctx = torch.cuda.stream(masked) if masked is not None else torch.cuda.stream(torch.cuda.current_stream())
+    ctx.__enter__()
     for name in args.shapes.split(","):
         n, H, W, Ci, Co, taps, res = SHAPES[name][:7]
         act = SHAPES[name][7] if len(SHAPES[name]) > 7 else None
