@@ -490,9 +490,16 @@ struct ThinCfg {
   static constexpr int WBUF = 3 * NT * 16;                   // nine 1-KiB tap tiles inside the 12 KiB that 3 x 256 lanes x 16 B write
   static constexpr int TBLOFF = 2 * XBUF + 2 * WBUF;
   static constexpr int LDS = TBLOFF + 128;
+  static constexpr int GNOFF = LDS, GNMAXC = 512;            // fused GroupNorm: scale[C], shift[C] of the workgroup's sample
+  static constexpr int LDS_GN = GNOFF + 2 * GNMAXC * 4;      // 77.9 KiB: still two workgroups per CU
 };
 
-template <typename T>
+// GN: GroupNorm(+SiLU) applied in place on the landed halo chunk (y = act(x * scale[n][c] + shift[n][c]), rounded to T exactly where
+// the GroupNorm kernel would round) — this layer reads 1 GB for 3 output channels and its VALU is idle, so the normalised tensor of
+// conv_norm_out need not exist: no GroupNorm launch, 2 of the 3.3 passes over the tensor gone.  Every lane transforms the pieces it
+// fetched itself (padding pieces stay zero: the reference pads the NORMALISED tensor); two barriers per chunk instead of one, so
+// that the next chunk's fetch is in flight while this one is transformed.
+template <typename T, bool GN>
 __global__ __launch_bounds__(256, 2) void conv3_thin_kernel(const IgemmArgs a, const HaloGeom g) {
   using Cfg = ThinCfg;
   constexpr int EPC = Elem<T>::EPC;
@@ -576,11 +583,43 @@ __global__ __launch_bounds__(256, 2) void conv3_thin_kernel(const IgemmArgs a, c
 #pragma unroll
   for (int j = 0; j < TM; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float* const gnp = reinterpret_cast<float*>(smem + Cfg::GNOFF);
+  if constexpr (GN) {
+    if (ng < g.n_img)
+      for (int c = t; c < Ctot; c += NT) {
+        gnp[c] = a.gn_scale[(size_t)ng * Ctot + c];
+        gnp[Ctot + c] = a.gn_shift[(size_t)ng * Ctot + c];
+      }
+  }
   issue(0);
   for (int cc = 0; cc < nchunks; ++cc) {
     hwait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                    // chunk cc is in for everyone; everyone is done with chunk cc - 1
     if (cc + 1 < nchunks) issue(cc + 1);
+    if constexpr (GN) {
+      const float* sc = gnp + cc * BKE + xlx * EPC;
+      const float* sh = sc + Ctot;
+      float scr[EPC], shr[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { scr[e] = sc[e]; shr[e] = sh[e]; }
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) {
+        if (pp[i] >= 0) {
+          chunk16* q = reinterpret_cast<chunk16*>(smem + (cc & 1) * Cfg::XBUF + (i * NT + t) * 16);
+          float f[EPC];
+          chunk_to_f<T>(*q, f);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float v = f[e] * scr[e] + shr[e];
+            if (a.gn_silu) v = silu_t<T>(v);
+            f[e] = v;
+          }
+          *q = f_to_chunk<T>(f);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): my in-place writes are in LDS
+      __builtin_amdgcn_s_barrier();                  // everyone's pieces of chunk cc are normalised
+    }
     const char* Xb = smem + (cc & 1) * Cfg::XBUF;
     const char* Wb = Wl + (cc & 1) * Cfg::WBUF;
 #pragma unroll
@@ -614,7 +653,8 @@ __global__ __launch_bounds__(256, 2) void conv3_thin_kernel(const IgemmArgs a, c
 // plain bias-only 3x3 stride-1 conv with at most 16 output channels on a power-of-two image of at least 16x16
 bool dc_conv3_thin_applicable(const IgemmArgs& a, int dtype) {
   static const bool off = getenv("DCAMD_NO_THIN") != nullptr;
-  if (off || a.taps != 9 || a.stride != 1 || a.upsample || a.act != DC_ACT_NONE || a.gate || a.rowvec || a.residual || a.gn_scale || a.src2) return false;
+  if (off || a.taps != 9 || a.stride != 1 || a.upsample || a.act != DC_ACT_NONE || a.gate || a.rowvec || a.residual || a.src2) return false;
+  if (a.gn_scale && a.C0 + a.C1 > ThinCfg::GNMAXC) return false;       // fused GroupNorm: the sample's affine table must fit its LDS slot
   if (a.Cout > 16) return false;
   const int H = a.Hin, W = a.Win;
   if (H < 16 || W < 16 || (H & (H - 1)) || (W & (W - 1))) return false;
@@ -755,9 +795,12 @@ int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s
 template <typename T>
 static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
   static bool attr_done = false;
-  auto kern = conv3_thin_kernel<T>;
+  const bool gn = a0.gn_scale != nullptr;
+  void (*kern)(const IgemmArgs, const HaloGeom) = gn ? conv3_thin_kernel<T, true> : conv3_thin_kernel<T, false>;
+  const int lds = gn ? ThinCfg::LDS_GN : ThinCfg::LDS;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ThinCfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_thin_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ThinCfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_thin_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ThinCfg::LDS_GN);
     attr_done = true;
   }
   IgemmArgs a = a0;
@@ -775,7 +818,8 @@ static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
   if (g.nxl > ThinCfg::NXL) { dc_set_error("conv3_thin: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
   const long long nblk = (long long)((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_thin: bad grid %lld", nblk); return DC_ERR_SHAPE; }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(ThinCfg::NT), ThinCfg::LDS, s, a, g);
+  if (gn && ni != 1) { dc_set_error("conv3_thin: the fused GroupNorm needs one sample per patch"); return DC_ERR_SHAPE; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(ThinCfg::NT), lds, s, a, g);
   return dc_check_launch("dc_igemm(conv3_thin)");
 }
 

@@ -326,7 +326,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
       return DC_ERR_UNSUPPORTED;
     }
   }
-  if (a.gn_scale && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
+  const bool thin_gn = a.gn_scale && !env_v1 && dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;   // conv_out: normalised in the halo
+  if (a.gn_scale && !thin_gn && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
     if (variant) { *variant = "gn-not-fusable"; return DC_ERR_UNSUPPORTED; }
     dc_set_error("dc_igemm: gn_scale/gn_shift given but this problem cannot take the fused GroupNorm prologue (see dc_igemm_gn_fusable)");
     return DC_ERR_UNSUPPORTED;

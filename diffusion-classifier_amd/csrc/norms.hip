@@ -456,6 +456,34 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a, float*
   }
 }
 
+// statistics-only mode with the producer's quad records: no sweep of the tensor at all — fold the records (gn_image_kernel's
+// order: parts outer, the group's quads inner, so the affine is bit-identical to what that kernel applies) and emit the
+// per-(sample, channel) scale / shift for a consumer that normalises on the fly (dc_igemm gn_scale / gn_shift)
+__global__ __launch_bounds__(256) void gn_qaffine_kernel(const GnArgs a, float* out_scale, float* out_shift) {
+  extern __shared__ __attribute__((aligned(16))) float st[];    // mean[groups], rstd[groups]
+  const int C = a.C0, n = blockIdx.x, t = threadIdx.x;
+  const int ns = a.map0 ? a.map0[n] : n;
+  const int cpg = C / a.groups, qpg = cpg >> 2, CQ = C >> 2;
+  for (int g = t; g < a.groups; g += 256) {
+    float S = 0.f, Q = 0.f;
+    for (int part = 0; part < a.qparts; ++part) {
+      const float2* w = reinterpret_cast<const float2*>(a.qstats) + ((size_t)ns * a.qparts + part) * CQ + g * qpg;
+      for (int q = 0; q < qpg; ++q) { const float2 v = w[q]; S += v.x; Q += v.y; }
+    }
+    const float cnt = (float)cpg * (float)a.HW;
+    const float mean = S / cnt;
+    st[g] = mean;
+    st[a.groups + g] = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + a.eps);
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cpg;
+    const float r = st[a.groups + g] * a.gamma[c];
+    out_scale[(size_t)n * C + c] = r;
+    out_shift[(size_t)n * C + c] = a.beta[c] - st[g] * r;
+  }
+}
+
 extern "C" int64_t dc_groupnorm_ws_floats(int32_t n, int32_t groups, int32_t splits) {
   return (int64_t)n * groups * splits * 2;
 }
@@ -471,7 +499,7 @@ extern "C" int32_t dc_groupnorm_splits(int32_t n, int32_t HW, int32_t C) {
 extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   DC_REQUIRE(p && p->x && p->gamma && p->beta && p->ws, DC_ERR_ARG, "dc_groupnorm: null pointer");
   const bool stats_only = p->y == nullptr;
-  if (stats_only) DC_REQUIRE(p->out_scale && p->out_shift && p->groups <= 64, DC_ERR_ARG, "dc_groupnorm: statistics-only mode needs out_scale/out_shift and groups <= 64");
+  if (stats_only) DC_REQUIRE(p->out_scale && p->out_shift && (p->groups <= 64 || p->qstats), DC_ERR_ARG, "dc_groupnorm: statistics-only mode needs out_scale/out_shift and groups <= 64");
   const int C1 = p->C1;
   const int C = p->C + C1;
   const int epc = 16 / dc_dtype_size(p->dtype);
@@ -487,7 +515,7 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   a.out_dtype = p->out_dtype; a.eps = p->eps;
   a.qstats = nullptr; a.qparts = 0; a.wsplits = p->splits;
   if (p->qstats) {
-    DC_REQUIRE(!stats_only && C1 == 0 && p->qparts > 0 && (C / p->groups) % 4 == 0 && ((uintptr_t)p->qstats & 7) == 0, DC_ERR_ARG,
+    DC_REQUIRE(C1 == 0 && p->qparts > 0 && (C / p->groups) % 4 == 0 && ((uintptr_t)p->qstats & 7) == 0, DC_ERR_ARG,
                "dc_groupnorm: qstats needs one source, qparts > 0 and (C/groups) %% 4 == 0 (C=%d groups=%d C1=%d)", C, p->groups, C1);
   }
   const int CP = C / epc;
@@ -500,6 +528,12 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   const long long nb = (long long)p->splits * p->n;
   DC_REQUIRE(nb < (1LL << 31), DC_ERR_SHAPE, "dc_groupnorm: grid too large");
   dim3 grid((unsigned)nb), blk(256);
+  if (stats_only && p->qstats) {
+    DC_REQUIRE(p->groups <= 4096, DC_ERR_SHAPE, "dc_groupnorm: groups=%d", p->groups);
+    a.qstats = p->qstats; a.qparts = p->qparts;
+    hipLaunchKernelGGL(gn_qaffine_kernel, dim3((unsigned)p->n), blk, lds_apply, s, a, p->out_scale, p->out_shift);
+    return dc_check_launch("dc_groupnorm(qaffine)");
+  }
   if (stats_only) {
     if (p->dtype == DC_F32) hipLaunchKernelGGL((gn_stats_kernel<float>), grid, blk, lds_stats, s, a);
     else if (p->dtype == DC_BF16) hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, blk, lds_stats, s, a);

@@ -203,7 +203,7 @@ class PlanBuilder:
                           out=fake, out_dtype=src0.dt, out_ld=Cout, src2=fake, W2=fake, C2=s2.C, ld2=s2.ld)
         return bool(L.lib().dc_igemm_side_ok(p))
 
-    def gn_fusable(self, src0, src1, Cout):
+    def gn_fusable(self, src0, src1, Cout, tile_n=128, out_dt=None):
         """Can a 3x3 stride-1 conv of these sources take the GroupNorm prologue (dc_igemm_gn_fusable)?"""
         if L.lib().dc_igemm_gn_fusable is None:
             return False
@@ -211,7 +211,7 @@ class PlanBuilder:
         p = L.IgemmParams(dtype=src0.dt, taps=9, stride=1, upsample=0, n_img=self.n[self._dom(src0, src1)], Hin=src0.H, Win=src0.W,
                           Hout=src0.H, Wout=src0.W, src0=fake, C0=src0.C, ld0=src0.ld, src1=fake if src1 is not None else None,
                           C1=src1.C if src1 is not None else 0, ld1=src1.ld if src1 is not None else 0, W=fake, Cout=Cout,
-                          tile_n=128, out=fake, out_dtype=src0.dt, out_ld=Cout)
+                          tile_n=tile_n, out=fake, out_dtype=src0.dt if out_dt is None else out_dt, out_ld=Cout)
         return bool(L.lib().dc_igemm_gn_fusable(p))
 
     def groupnorm_stats(self, name, x0, gamma, beta, groups, eps, x1=None):
@@ -227,9 +227,18 @@ class PlanBuilder:
         f = dict(x=x0, map0=self._map(x0, dom), x1=x1, map1=self._map(x1, dom), y=None, dtype=x0.dt, out_dtype=x0.dt,
                  n=n, HW=HW, C=x0.C, C1=x1.C if x1 is not None else 0, groups=groups, silu=0, splits=splits, eps=eps,
                  gamma=gamma, beta=beta, ws=ws, out_scale=sc, out_shift=sh)
-        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1], [sc, sh, ws],
-                   dict(name=name, family="groupnorm_stats", flops=0.0, bytes=1.0 * n * HW * Cc * DT_SIZE[x0.dt]))
+        qs = None
+        if self.qstats_ok(x0, x1, groups, dom):    # the producer's quad records: the affine is formed without reading the tensor
+            qs = x0.qs[0]
+            f.update(qstats=qs, qparts=x0.qs[1])
+        self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1, qs], [sc, sh, ws],
+                   dict(name=name, family="groupnorm_stats", flops=0.0, bytes=(0.0 if qs is not None else 1.0 * n * HW * Cc * DT_SIZE[x0.dt])))
         return sc, sh
+
+    @staticmethod
+    def qstats_ok(x0, x1, groups, dom):
+        """Does x0 carry quad statistics its GroupNorm can use (single source, same domain, groups made of whole quads)?"""
+        return x1 is None and x0.qs is not None and ((x0.C // groups) % 4 == 0) and x0.dom == dom
 
     def groupnorm(self, name, x0, gamma, beta, groups, eps, silu, x1=None):
         dom = self._dom(x0, x1)
@@ -244,7 +253,7 @@ class PlanBuilder:
                  n=n, HW=HW, C=x0.C, C1=x1.C if x1 is not None else 0, groups=groups, silu=int(silu),
                  splits=splits, eps=eps, gamma=gamma, beta=beta, ws=ws)
         qs = None
-        if x1 is None and x0.qs is not None and (Cc // groups) % 4 == 0 and x0.dom == dom:
+        if self.qstats_ok(x0, x1, groups, dom):
             qs = x0.qs[0]
             f.update(qstats=qs, qparts=x0.qs[1])
         self._emit(L.OP_GROUPNORM, L.GroupnormParams, f, [x0, x1, qs], [out, ws],
@@ -625,6 +634,7 @@ class UNetPlan:
         # the standalone apply pass on cfg2 (the in-loop transform costs the conv more than the pass it removes),
         # so it stays opt-in until the transform overlaps the MFMA stream.
         fuse_gn = os.environ.get("DCAMD_GN_FUSION") is not None
+        fuse_gn_out = os.environ.get("DCAMD_NO_GN_OUT_FUSION") is None
         split_skips = os.environ.get("DCAMD_NO_SKIP_SPLIT") is None
         fold_short = os.environ.get("DCAMD_NO_SHORT_FOLD") is None
         # 3x3 convs also emit the (sum, sumsq) quad statistics of their output, so the GroupNorm that follows streams the
@@ -818,9 +828,17 @@ class UNetPlan:
                     h = pb.igemm(key, h, pb.const(P[key + ".w4"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]), qstats=use_qs, up4=True)
                 else:
                     h = pb.igemm(key, h, pb.const(P[key + ".w"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]), qstats=use_qs)
-        h = pb.groupnorm("conv_norm_out", h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps, True)
-        pred = pb.igemm("conv_out", h, pb.const(P["conv_out.w"]), cfg.out_channels, taps=9, bias=pb.const(P["conv_out.b"]),
-                        out_dt=L.DC_F32, tile_n=32 if cfg.out_channels <= 32 else 128)
+        tn_out = 32 if cfg.out_channels <= 32 else 128
+        if (fuse_gn_out and pb.qstats_ok(h, None, G, h.dom) and pb.gn_fusable(h, None, cfg.out_channels, tile_n=tn_out, out_dt=L.DC_F32)):
+            # conv_norm_out + SiLU inside conv_out's halo load (the thin-output conv reads ~1 GB for 3 channels and its VALU is idle):
+            # the affine comes from the last conv's quad records, the normalised tensor never exists, one launch instead of two
+            aff = pb.groupnorm_stats("conv_norm_out", h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps)
+            pred = pb.igemm("conv_out", h, pb.const(P["conv_out.w"]), cfg.out_channels, taps=9, bias=pb.const(P["conv_out.b"]),
+                            out_dt=L.DC_F32, tile_n=tn_out, gn=(aff[0], aff[1], True))
+        else:
+            h = pb.groupnorm("conv_norm_out", h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps, True)
+            pred = pb.igemm("conv_out", h, pb.const(P["conv_out.w"]), cfg.out_channels, taps=9, bias=pb.const(P["conv_out.b"]),
+                            out_dt=L.DC_F32, tile_n=tn_out)
         if pred.dom != "unit":
             raise L.DcamdError("backbone has no class-conditioned layer: nothing to score per class")
         self.pred = pred

@@ -103,7 +103,8 @@ typedef struct {
   void* out; int32_t out_dtype, out_ld;
   /* fused GroupNorm(+SiLU) prologue on the A operand: a[n,y,x,c] := act(a*gn_scale[n][c] + gn_shift[n][c]) for
    * real pixels (conv padding stays 0).  Only where dc_igemm_gn_fusable() says so (3x3 halo kernel, one sample
-   * per workgroup, C0+C1 <= 512); NULL otherwise. */
+   * per workgroup, C0+C1 <= 512; or the thin-output 3x3 conv, Cout <= 16 on images >= 16x16: conv_norm_out + conv_out
+   * as one launch, rounded exactly as the GroupNorm kernel rounds); NULL otherwise. */
   const float* gn_scale; const float* gn_shift; int32_t gn_silu, pad3_;
   /* optional 1x1 side source summed into the same output (a ResNet's conv_shortcut folded into its conv2):
    * out += sum_c A2[row, c] * W2p[co, c], A2 = src2 [*, Hout, Wout, C2] read through map2, W2p packed [Cout_pad][C2].
@@ -183,7 +184,8 @@ typedef struct {
    * fly (gn_scale / gn_shift) — the normalised tensor is then never written to HBM. */
   float* out_scale; float* out_shift;
   /* statistics already formed by the producer of x (dc_igemm_params.qstats; qparts parts per sample): single source
-   * (C1 == 0), (C/groups) a multiple of 4.  The statistics sweep is skipped.  NULL / 0 otherwise. */
+   * (C1 == 0), (C/groups) a multiple of 4.  The statistics sweep is skipped; in statistics-only mode the tensor is not
+   * read at all (x is then only the sample count's witness).  NULL / 0 otherwise. */
   const float* qstats; int32_t qparts, pad_;
 } dc_groupnorm_params;
 int dc_groupnorm(const dc_groupnorm_params* p, dc_stream s);

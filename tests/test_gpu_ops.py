@@ -584,6 +584,63 @@ def test_conv3x3_with_fused_groupnorm_prologue(dt, concat):
     assert lib.dc_igemm_gn_fusable(p) == 0 and lib.dc_igemm(p, L.stream_ptr()) == -6
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("shape", [(3, 32, 32, 128, 3), (2, 16, 16, 256, 12), (2, 64, 32, 128, 4)])
+def test_thin_conv_with_groupnorm_from_quad_statistics(dt, shape):
+    """conv_norm_out + conv_out as ONE launch: the producer conv's quad records -> statistics-only GroupNorm (no sweep of the tensor)
+    -> thin-output conv normalising its halo chunks in place.  Must equal GroupNorm kernel + thin conv BIT FOR BIT (same affine,
+    same rounding points), and torch within the dtype's tolerance."""
+    torch.manual_seed(33)
+    n, H, W, C, Co = shape
+    g = E.bke(dt)
+    q = lambda t: t.to(TD[dt]).float()
+    lib = L.lib()
+    # producer: a 3x3 conv that also writes the quad statistics of its output
+    x0 = q(torch.randn(n, 2 * g, H, W))
+    wp_ = q(torch.randn(C, 2 * g, 3, 3) / (3 * (2 * g) ** 0.5))
+    a0, Wpp = nhwc(x0, dt), E.pack_conv3x3(wp_, dt, DEV)
+    h = torch.empty(n, H, W, C, dtype=TD[dt], device=DEV)
+    kw = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=2 * g, W=ptr(Wpp), Cout=C,
+              tile_n=128, out=ptr(h), out_dtype=dt, out_ld=C)
+    parts = lib.dc_igemm_qstats_parts(L.IgemmParams(**kw))
+    assert parts > 0
+    qs = torch.zeros(n, parts, C // 4, 2, device=DEV)
+    run_igemm(qstats=ptr(qs), **kw)
+    gamma, beta = (torch.randn(C) * 0.5 + 1).to(DEV), torch.randn(C).to(DEV)
+    splits = lib.dc_groupnorm_splits(n, H * W, C)
+    ws = torch.zeros(lib.dc_groupnorm_ws_floats(n, 32, splits), device=DEV)
+    gk = dict(x=ptr(h), dtype=dt, out_dtype=dt, n=n, HW=H * W, C=C, C1=0, groups=32, splits=splits, eps=1e-5, gamma=ptr(gamma), beta=ptr(beta),
+              ws=ptr(ws), qstats=ptr(qs), qparts=parts)
+    # unfused: GroupNorm(+SiLU) kernel, then the thin conv
+    y = torch.empty_like(h)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(y=ptr(y), silu=1, **gk), L.stream_ptr()), "gn")
+    w = q(torch.randn(Co, C, 3, 3) / (3 * C ** 0.5))
+    b = torch.randn(Co).to(DEV)
+    Wo = E.pack_conv3x3(w, dt, DEV, tile_n=32)
+    o_ref = torch.full((n, H, W, Co), float("nan"), device=DEV)
+    ck = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, C0=C, W=ptr(Wo), Cout=Co, tile_n=32,
+              bias=ptr(b), out_dtype=L.DC_F32, out_ld=Co)
+    pu = L.IgemmParams(src0=ptr(y), out=ptr(o_ref), **ck)
+    assert lib.dc_igemm_variant(pu).decode().startswith("conv3_thin")
+    L.check(lib.dc_igemm(pu, L.stream_ptr()), "thin conv")
+    # fused: affine from the quad records only, normalised inside the conv
+    sc, sh = torch.zeros(n, C, device=DEV), torch.zeros(n, C, device=DEV)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(y=None, silu=0, out_scale=ptr(sc), out_shift=ptr(sh), **gk), L.stream_ptr()), "gn affine")
+    o = torch.full((n, H, W, Co), float("nan"), device=DEV)
+    pf = L.IgemmParams(src0=ptr(h), out=ptr(o), gn_scale=ptr(sc), gn_shift=ptr(sh), gn_silu=1, **ck)
+    assert lib.dc_igemm_gn_fusable(pf) == 1 and lib.dc_igemm_variant(pf).decode().startswith("conv3_thin")
+    L.check(lib.dc_igemm(pf, L.stream_ptr()), "fused thin conv")
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    if H * W * C * (4 if dt == L.DC_F32 else 2) < (1 << 20):
+        assert torch.equal(o, o_ref)
+    else:       # samples of 1 MiB and more: the GroupNorm kernel folds the quad records in gn_qfold_kernel's order, the affine in gn_image_kernel's
+        assert maxrel(o, o_ref) < (1e-5 if dt == L.DC_F32 else 4e-3), maxrel(o, o_ref)
+    hn = F.silu(F.group_norm(h.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5))
+    ref = F.conv2d(q(hn), w.to(DEV), b, padding=1).permute(0, 2, 3, 1)
+    assert maxrel(o, ref) < {L.DC_F32: 3e-5, L.DC_BF16: 1.5e-2, L.DC_F16: 3e-3}[dt], maxrel(o, ref)
+
+
 def test_groupnorm_span_kernel_opt_in():
     """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
     test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
