@@ -249,3 +249,41 @@ def test_cfg3_inputs_are_the_haar_transform_of_the_image():
     rel = ((got_e - ref_e).abs() / ref_e).max().item()
     print(f"cfg3 bf16 classify (1 trial x 2 classes) per-cell eps-MSE max rel err: {rel:.2e}")
     assert rel < 2e-2, rel
+
+
+def test_cfg2_full_grid_properties_at_bench_size():
+    """BASELINE config 2 at the size `bench.py` times (10 classes x 50 trials, bf16, philox noise, 4 images = 2000 unit-forwards),
+    through properties that need no oracle: (a) a repeated call is bit-identical and the label is the arg-min of the mean error;
+    (b) the per-cell errors do not depend on how many units share a launch; (c) a two-stage schedule evaluates exactly the cells
+    the reference's pruning (:718-721) leaves — stage 1 = the first trials of the full grid, later trials only for each image's
+    k best classes, with the very same per-cell errors — and labels from the pruned grid only.  (The two-rank deal of the same
+    grid: tests/test_gpu_dist.py.)"""
+    cfg = dict(CFG2, evaluation_per_stage=[50], compute_dtype="bf16")
+    _, dc = _cfg2_pair(31, cfg)
+    dc = dc.to(DEV)
+    torch.manual_seed(32)
+    x = (torch.rand(4, 3, 32, 32) * 2 - 1).to(DEV)
+    t = torch.rand(50, 4)
+    l1, e1 = dc.classify(x, t=t, rng="philox", seed=7, return_errors=True)
+    l2, e2 = dc.classify(x, t=t, rng="philox", seed=7, return_errors=True)
+    assert e1.shape == (4, 10, 50) and torch.isfinite(e1).all()
+    assert torch.equal(e1, e2) and torch.equal(l1, l2)                                   # (a)
+    assert l1.cpu().tolist() == e1.cpu().mean(2).argmin(1).tolist()
+    dc.config.units_per_launch = 500
+    l3, e3 = dc.classify(x, t=t, rng="philox", seed=7, return_errors=True)
+    assert torch.equal(e1, e3) and torch.equal(l1, l3)                                   # (b)
+    # (c) two stages: 10 trials for all classes, then trials 10..49 for the 5 best of each image
+    cfg2s = dict(cfg, n_stages=2, evaluation_per_stage=[10, 50], n_keep_per_stage=[5, 1])
+    _, dcb = _cfg2_pair(31, cfg2s)
+    dcb = dcb.to(DEV)
+    lb, eb = dcb.classify(x, t=t, rng="philox", seed=7, return_errors=True)
+    e1c, ebc = e1.cpu(), eb.cpu()
+    assert torch.equal(ebc[:, :, :10], e1c[:, :, :10])
+    keep = e1c[:, :, :10].mean(2).topk(5, dim=1, largest=False).indices
+    kept = torch.zeros(4, 10, dtype=torch.bool)
+    kept.scatter_(1, keep, True)
+    assert torch.equal(torch.isfinite(ebc[:, :, 10:]).all(2), kept)
+    assert torch.equal(torch.isfinite(ebc[:, :, 10:]).any(2), kept)
+    assert torch.equal(ebc[:, :, 10:][kept], e1c[:, :, 10:][kept])
+    masked = torch.where(kept, e1c.mean(2), torch.full((4, 10), float("inf")))
+    assert lb.cpu().tolist() == masked.argmin(1).tolist()

@@ -22,11 +22,11 @@ def _free_port():
     return p
 
 
-def _launch(world, tmp_path):
+def _launch(world, tmp_path, arch="small"):
     port = _free_port()
-    outs = [str(tmp_path / f"w{world}_r{r}.npz") for r in range(world)]
+    outs = [str(tmp_path / f"{arch}_w{world}_r{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), outs[r]], env=env) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), outs[r], arch], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     return [dict(np.load(o)) for o in outs]
@@ -41,3 +41,15 @@ def test_hip_runner_world_size_2_is_bit_identical_to_world_size_1(tmp_path):
     for r in two:
         for k in ("lab", "err", "lab_p", "err_p"):
             np.testing.assert_array_equal(r[k], one[k])            # bit-identical errors and labels on every rank
+
+
+def test_cfg2_architecture_bf16_world_size_3_is_bit_identical_to_world_size_1(tmp_path):
+    """BASELINE config 2's UNet in bf16 with 10 classes (class-shared trunk and skip halves in the plan), two stages, the 21 + 12
+    (trial, image) pairs of the stages dealt to THREE ranks (uneven shares): every rank must end with the single-process errors
+    and labels, bit for bit."""
+    one = _launch(1, tmp_path, "cfg2")[0]
+    three = _launch(3, tmp_path, "cfg2")
+    assert np.isinf(one["err"]).any() and np.isfinite(one["err"]).any()
+    for r in three:
+        for k in ("lab", "err", "lab_p", "err_p"):
+            np.testing.assert_array_equal(r[k], one[k])
