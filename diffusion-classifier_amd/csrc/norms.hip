@@ -567,11 +567,14 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   static const size_t qsplit_min = getenv("DCAMD_GN_QSPLIT_MIN") ? (size_t)atoll(getenv("DCAMD_GN_QSPLIT_MIN")) : (1u << 20);
   const bool qsplit = p->qstats != nullptr && img_bytes >= qsplit_min;
   // producer statistics + a sample that divides into whole 16 KiB spans of one column set: gn_span_kernel (a function of (HW, C) only).
-  // OPT-IN (DCAMD_GN_SPAN): alone it streams 5.9-6.4 TB/s against gn_image_kernel's 5.2-5.6, and inside the scoring step GroupNorm
-  // drops from 11.1 to 10.1 ms — but the convolutions that follow slow down by the same amount (cfg2: 77.7 -> 77.9 ms per step):
-  // every kernel of the step runs at the socket's power cap (~1.37 kW, 2.08-2.18 GHz by rocm-smi), so a phase that moves the same
-  // bytes in less time only hands a hotter chip to the next phase.  DESIGN.md §6b.
-  static const bool no_span = getenv("DCAMD_GN_SPAN") == nullptr;
+  // Default for samples of 1 MiB and more (the CheXpert / IPMSA plans, where it replaces gn_apply_kernel's split sweep: cfg3 +0.8 %,
+  // cfg4 +1.7 % per step); DCAMD_GN_SPAN forces it for every size, DCAMD_GN_NO_SPAN turns it off.  For the small samples of cfg2 it
+  // is NOT the default: alone it streams 5.9-6.4 TB/s against gn_image_kernel's 5.2-5.6, and inside the scoring step GroupNorm drops
+  // from 11.1 to 10.1 ms — but the convolutions that follow slow down by the same amount (77.7 -> 77.9 ms per step): every kernel of
+  // that step runs at the socket's power cap (~1.37 kW, 2.08-2.18 GHz by rocm-smi), so a phase that moves the same bytes in less
+  // time only hands a hotter chip to the next phase.  DESIGN.md §6c.
+  static const bool span_all = getenv("DCAMD_GN_SPAN") != nullptr, span_never = getenv("DCAMD_GN_NO_SPAN") != nullptr;
+  const bool no_span = span_never || !(span_all || qsplit);      // default: only the samples of 1 MiB and more, which had the split apply sweep
   const long long chunks = (long long)p->HW * CP;
   if (!no_span && p->qstats && C1 == 0 && CP <= 256 && (CP & (CP - 1)) == 0 && chunks % 1024 == 0 && p->groups <= 2048 &&
       (long long)p->n * (chunks / 1024) < (1LL << 31)) {
