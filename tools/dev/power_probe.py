@@ -22,7 +22,16 @@ n, H, W, Ci, Co = 4000, 32, 32, 128, 128
 x = torch.randn(n, H, W, Ci, device=dev).to(td)
 out = torch.empty(n, H, W, Co, device=dev, dtype=td)
 b = torch.randn(2048, device=dev)
-if which == "geglu":
+if which in ("dit_qkv", "dit_fc2"):
+    K, N = (768, 2304) if which == "dit_qkv" else (3072, 768)
+    td16 = torch.float16
+    Wp = E.pack_matrix(torch.randn(N, K) / K ** 0.5, L.DC_F16, dev)
+    xg = torch.randn(1000, 32, 32, K, device=dev).to(td16)
+    og = torch.empty(1000, 32, 32, N, device=dev, dtype=td16)
+    p = L.IgemmParams(dtype=L.DC_F16, taps=1, stride=1, upsample=0, n_img=1000, Hin=32, Win=32, Hout=32, Wout=32, src0=xg.data_ptr(), C0=K,
+                      W=Wp.data_ptr(), Cout=N, tile_n=128, bias=b.data_ptr() if N <= 2048 else None, out=og.data_ptr(), out_dtype=L.DC_F16, out_ld=N)
+    fn, flops, nbytes = lib.dc_igemm, 2.0 * 1000 * 1024 * K * N, 0
+elif which == "geglu":
     Wp = E.pack_matrix(torch.randn(2048, 256) / 16, dt, dev)
     xg = torch.randn(8000, 8, 8, 256, device=dev).to(td)
     og = torch.empty(8000, 8, 8, 1024, device=dev, dtype=td)
@@ -61,9 +70,9 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 while time.time() - t0 < secs:
     if which != "idle":
-        for _ in range(200):
+        for _ in range(200 if not which.startswith("dit") else 40):
             L.check(fn(p, L.stream_ptr()))
-        launches += 200
+        launches += 200 if not which.startswith("dit") else 40
     if time.time() - t0 > 1.0:
         samples.append(smi())
     if which == "idle":
