@@ -13,7 +13,7 @@ struct IgemmArgs {
   const float* gn_scale; const float* gn_shift; int gn_silu;
   const void* src2; const int32_t* map2; const void* W2; int C2, ld2;   // 1x1 side source (conv3_halo only)
   float ln_eps;             // > 0: row LayerNorm of the A operand (igemm_xreg only)
-  float* qstats;            // per (sample, part, channel quad) (sum, sumsq) of the stored output (conv3_halo only)
+  float* qstats;            // per (sample, part, channel quad) (mean, M2) of the stored output (conv3_halo only)
   int C0, C1, ld0, ld1, rowvec_ld, gate_ld, res_dtype, res_ld, out_dtype, out_ld, act;
   int taps, stride, upsample, Hin, Win, Hout, Wout, Cout;
   int M, Ktot, c0chunks, cpt, nk, tiles_m, tiles_n;

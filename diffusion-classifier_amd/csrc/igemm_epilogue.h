@@ -62,6 +62,7 @@ struct EpiNoBias {
 // quad statistics for a following GroupNorm (IgemmArgs::qstats).  QsFn::on selects the code; qsfn(half, n, part):
 // the output sample and part index of pixel fragments [4 half, 4 half + 4) of the wave (wave-uniform), false when that
 // sample does not exist; qsfn.whole(): both halves belong to the same (sample, part) and are written as one record.
+template <int V> struct EpiIC { static constexpr int value = V; };
 struct EpiNoQs {
   static constexpr bool on = false;
   __device__ __forceinline__ bool operator()(int, int&, int&) const { return false; }
@@ -212,39 +213,23 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     }
   }
   DC_STAMP(5);
-  // ---- quad statistics of the values about to be stored: per lane the
-  // two 4-channel quads of each run, summed over the lane's pixels of each half; then over the 16 pixel lanes (lane & 15)
-  // by xor-shuffles; lanes with (lane & 15) == 0 write one 16-byte record {s0, q0, s1, q1} per run.  Fixed order: the
-  // result depends on the tile geometry only.
+  // ---- quad statistics of the values about to be stored, for the GroupNorm that consumes the tensor: per (sample, part, quad
+  // of 4 consecutive channels) the MEAN and the centred second moment M2 = sum (v - mean)^2 over the quad's 4 x npx values —
+  // not (sum, sum of squares), whose difference cancels when |mean| >> std.  Shifted sums: every 16-lane row of the wave (16
+  // pixels x 8 channels of a fragment row) takes, per quad, the first pixel's first channel as the pivot (DPP row_share:0),
+  // accumulates S' = sum (v - pivot) and Q' = sum (v - pivot)^2 over the lane's pixels (two adjacent accumulator registers per
+  // packed instruction), reduces them over the row's 16 lanes with four DPP adds, and the row's first lane forms
+  // mean = pivot + S'/n, M2 = Q' - S'^2/n and writes one 16-byte record pair {mean0, M2_0, mean1, M2_1} per run.  What is left
+  // inside S' and Q' is the spread BETWEEN the channels of a quad, which is part of the group's variance anyway.
+  // Fixed order: the result depends on the tile geometry only.  The fp32 values are taken BEFORE the rounding to T (the
+  // re-conversion cost as much as the sums): they differ from the stored tensor's statistics by ~2^-9 / sqrt(count) relative.
   if constexpr (QsFn::on) {
     static_assert(!QsFn::on || (TM == 8 && ACT != DC_ACT_GEGLU), "quad statistics: 128-pixel wave tiles, plain epilogue");
     if (a.qstats) {
       typedef __attribute__((ext_vector_type(2))) float f32x2;    // two adjacent accumulator registers: v_pk_add_f32 / v_pk_fma_f32
-      f32x2 qsum[2][NK][2], qsq[2][NK][2];             // [half][run][quad]: (even, odd) components, folded at the end
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-          for (int qd = 0; qd < 2; ++qd) { qsum[h][k][qd] = f32x2{0.f, 0.f}; qsq[h][k][qd] = f32x2{0.f, 0.f}; }
-      // no per-pixel / per-run masks: a pixel is only ever invalid together with its whole sample, whose record is not
-      // written (qsfn returns false), and runs past Cout are not written either.  The fp32 values are taken BEFORE the
-      // rounding to T (the re-conversion cost as much as the sums): the statistics differ from those of the stored
-      // tensor by ~2^-9 / sqrt(count) relative, far below the 16-bit resolution of the normalised output.
-      // Operands are register pairs (c, c+1) of one accumulator fragment = one quad, so no moves are needed.
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-          for (int qd = 0; qd < 2; ++qd)
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-              const f32x2 v = {acc[2 * k + qd][j][e], acc[2 * k + qd][j][e + 1]};
-              qsum[j >> 2][k][qd] += v;
-              qsq[j >> 2][k][qd] += v * v;
-            }
-      const bool whole = qsfn.whole();
+      auto share0 = [](float v) {                                 // the value lane 0 of my 16-lane row holds
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xF, 0xF, true));
+      };
       // sum over the 16 pixel lanes of a row of the wave: four DPP adds (xor 1, xor 2, half-row mirror, row mirror)
       auto row_sum = [](float v) {
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -253,14 +238,39 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
         return v;
       };
-      auto emit = [&](int h, const f32x2 (&sm)[NK][2], const f32x2 (&sq)[NK][2]) {
+      // one (sample, part) record set from pixel fragments [J0, J1) of the wave
+      auto emit = [&](auto j0c, auto j1c, int h) {
+        constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+        float piv[NK][2];
+        f32x2 sm[NK][2], sq[NK][2];                               // [run][quad]: (even, odd) register pairs, folded at the end
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int qd = 0; qd < 2; ++qd) {
+            piv[k][qd] = share0(acc[2 * k + qd][J0][0]);
+            sm[k][qd] = f32x2{0.f, 0.f}; sq[k][qd] = f32x2{0.f, 0.f};
+          }
+#pragma unroll
+        for (int j = J0; j < J1; ++j)
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                const f32x2 d = f32x2{acc[2 * k + qd][j][e], acc[2 * k + qd][j][e + 1]} - f32x2{piv[k][qd], piv[k][qd]};
+                sm[k][qd] += d;
+                sq[k][qd] += d * d;
+              }
+        const float inv_n = 1.0f / (float)((J1 - J0) * 16 * 4);    // values per quad record
         float r[NK][4];
 #pragma unroll
         for (int k = 0; k < NK; ++k)
 #pragma unroll
           for (int qd = 0; qd < 2; ++qd) {
-            r[k][2 * qd] = row_sum(sm[k][qd][0] + sm[k][qd][1]);
-            r[k][2 * qd + 1] = row_sum(sq[k][qd][0] + sq[k][qd][1]);
+            const float S = row_sum(sm[k][qd][0] + sm[k][qd][1]), Q = row_sum(sq[k][qd][0] + sq[k][qd][1]);
+            r[k][2 * qd] = piv[k][qd] + S * inv_n;
+            r[k][2 * qd + 1] = fmaxf(Q - S * S * inv_n, 0.f);
           }
         int n = 0, part = 0;
         if ((threadIdx.x & 15) == 0 && qsfn(h, n, part)) {
@@ -271,16 +281,10 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
                   f32x4{r[k][0], r[k][1], r[k][2], r[k][3]};
         }
       };
-      if (whole) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-          for (int qd = 0; qd < 2; ++qd) { qsum[0][k][qd] += qsum[1][k][qd]; qsq[0][k][qd] += qsq[1][k][qd]; }
-        emit(0, qsum[0], qsq[0]);
-      } else {
-        emit(0, qsum[0], qsq[0]);
-        emit(1, qsum[1], qsq[1]);
-      }
+      // no per-pixel / per-run masks: a pixel is only ever invalid together with its whole sample, whose record is not
+      // written (qsfn returns false), and runs past Cout are not written either
+      if (qsfn.whole()) emit(EpiIC<0>{}, EpiIC<TM>{}, 0);
+      else { emit(EpiIC<0>{}, EpiIC<TM / 2>{}, 0); emit(EpiIC<TM / 2>{}, EpiIC<TM>{}, 1); }
     }
   }
   // ---- phase B: conversions and stores only (one straight-line sequence per output type) ----

@@ -9,9 +9,10 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ GroupNorm -----
-// Two launches. stats: grid (splits, n); each block reduces its pixel slice of one sample to
-// per-group (sum, sumsq) partials.  apply: same grid; each block folds the `splits` partials of
-// its sample in fixed order, then normalises (+affine, +SiLU) its pixel slice.
+// Statistics are carried as (mean, M2 = sum (v - mean)^2) of value sets — per thread, per split, per producer record — and
+// merged with Chan's update in a fixed order; the per-thread sums are SHIFTED by the thread's first value.  The textbook
+// sum / sum-of-squares form cancels when |mean| >> std (fp32: var off by ~1e-7 * mean^2 / var relative), which real
+// checkpoints with large activation offsets would have turned into parity drift; this form is as robust as torch's own.
 // The input may be a channel-concat of two sources (skip connections are never materialised).
 struct GnArgs {
   const void* x0; const int32_t* map0; const void* x1; const int32_t* map1;
@@ -20,6 +21,38 @@ struct GnArgs {
   const float* qstats; int qparts;      // statistics formed by the producer (dc_igemm_params.qstats): no statistics sweep
   int wsplits;                          // partial records per sample in ws (= splits, or 1 after gn_qfold_kernel)
 };
+
+// running (count, mean, M2); add() merges another set (Chan et al.), in the order the caller walks — fixed everywhere below
+struct GnAcc {
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  __device__ __forceinline__ void add(float n2, float mean2, float m22) {
+    if (n2 <= 0.f) return;
+    const float nt = n + n2, d = mean2 - mean, w = n2 / nt;
+    mean += d * w;
+    m2 += m22 + d * d * (n * w);
+    n = nt;
+  }
+  __device__ __forceinline__ float var() const { return n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f; }
+};
+// merge of many (count, mean, M2) sets in ONE pass without a division per set: shifted by the first set's mean,
+// N = sum n, S1 = sum n d, S3 = sum n d^2 (d = mean - pivot), S2 = sum M2  ->  mean = pivot + S1/N, M2 = S2 + S3 - S1^2/N
+struct GnMerge {
+  float piv = 0.f, N = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f;
+  bool have = false;
+  __device__ __forceinline__ void add(float n, float mean, float m2) {
+    if (n <= 0.f) return;
+    if (!have) { piv = mean; have = true; }
+    const float d = mean - piv;
+    N += n; S1 += n * d; S3 += n * d * d; S2 += m2;
+  }
+  __device__ __forceinline__ GnAcc result() const {
+    GnAcc A;
+    if (N > 0.f) { const float iN = 1.0f / N; A.n = N; A.mean = piv + S1 * iN; A.m2 = S2 + fmaxf(S3 - S1 * S1 * iN, 0.f); }
+    return A;
+  }
+};
+// pixels [p0, p1) of split k of `splits` over HW pixels (the same formula on the writing and on the reading side)
+__device__ __forceinline__ int gn_split_lo(int HW, int k, int splits) { return (int)((long long)HW * k / splits); }
 
 template <typename T>
 __device__ __forceinline__ const chunk16* gn_src(const GnArgs& a, int n, int col, int CP0, size_t pix_in_img, int& dummy) {
@@ -32,73 +65,126 @@ __device__ __forceinline__ const chunk16* gn_src(const GnArgs& a, int n, int col
   return reinterpret_cast<const chunk16*>(reinterpret_cast<const T*>(a.x1) + ((size_t)ns * a.HW + pix_in_img) * a.C1) + (col - CP0);
 }
 
+// fold the `wsplits` (mean, M2) records of (sample n, group g) in ws, in split order
+__device__ __forceinline__ GnAcc gn_fold_ws(const GnArgs& a, int n, int g, int cpg) {
+  GnAcc A;
+  for (int k = 0; k < a.wsplits; ++k) {
+    const float2 v = reinterpret_cast<const float2*>(a.ws)[((size_t)n * a.wsplits + k) * a.groups + g];
+    A.add((float)cpg * (float)(gn_split_lo(a.HW, k + 1, a.wsplits) - gn_split_lo(a.HW, k, a.wsplits)), v.x, v.y);
+  }
+  return A;
+}
+// fold the producer's quad records of group g (rec: [part][C/4] float2 (mean, M2) of the sample, each over nq = 4 * HW / qparts
+// values): equal counts, so mean = average of the means and M2 = sum M2_r + nq * sum (mean_r - mean)^2.  One pass, parts outer,
+// the group's quads inner, the means shifted by the first record's (what is left inside the shifted sums is the spread of the
+// record means, which is part of the group's variance): as many loads as the sum / sum-of-squares form had, no division per record
+__device__ __forceinline__ GnAcc gn_fold_rec(const float2* rec, int qparts, int CQ, int g, int qpg, float nq) {
+  const float piv = rec[g * qpg].x;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int part = 0; part < qparts; ++part)
+    for (int q = g * qpg; q < (g + 1) * qpg; ++q) {
+      const float2 v = rec[(size_t)part * CQ + q];
+      const float d = v.x - piv;
+      s1 += d; s3 += d * d; s2 += v.y;
+    }
+  const float R = (float)(qparts * qpg), iR = 1.0f / R;
+  GnAcc A;
+  A.n = R * nq;
+  A.mean = piv + s1 * iR;
+  A.m2 = s2 + nq * fmaxf(s3 - s1 * s1 * iR, 0.f);
+  return A;
+}
+
+// Two launches for samples too large for one workgroup.  stats: grid (splits, n); each block reduces its pixel slice of one
+// sample to per-group (mean, M2) partials.  apply: same grid; each block folds the `splits` partials of its sample in fixed
+// order, then normalises (+affine, +SiLU) its pixel slice.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
   constexpr int EPC = Elem<T>::EPC;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][PL][Cround]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][PL][C]: per-thread mean, M2
   const int C = a.C0 + a.C1;
   const int CP = C / EPC, CP0 = a.C0 / EPC;
   int TPR = 1; while (TPR < CP && TPR < 256) TPR <<= 1;   // threads per pixel row (pow2 <= 256)
   const int PL = 256 / TPR;                                // pixel lanes
   const int npass = (CP + 255) / 256;                      // column passes when CP > 256
   const int t = threadIdx.x, n = blockIdx.x / a.splits, s = blockIdx.x % a.splits;
-  const int p0 = (int)((long long)a.HW * s / a.splits), p1 = (int)((long long)a.HW * (s + 1) / a.splits);
+  const int p0 = gn_split_lo(a.HW, s, a.splits), p1 = gn_split_lo(a.HW, s + 1, a.splits);
   const int tc = t % TPR, pl = t / TPR;
   float* rs = red; float* rq = red + PL * C;
   int dummy = 0;
   for (int pass = 0; pass < npass; ++pass) {
     const int col = pass * 256 + tc;
-    float sm[EPC], sq[EPC];
+    if (col >= CP) continue;
+    float pv[EPC], sm[EPC], sq[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
-    if (col < CP) {
-      for (int p = p0 + pl; p < p1; p += PL) {
-        const chunk16 c = *gn_src<T>(a, n, col, CP0, (size_t)p, dummy);
-        float f[EPC];
-        chunk_to_f<T>(c, f);
+    for (int e = 0; e < EPC; ++e) { pv[e] = 0.f; sm[e] = 0.f; sq[e] = 0.f; }
+    int cnt = 0;
+    for (int p = p0 + pl; p < p1; p += PL) {
+      float f[EPC];
+      chunk_to_f<T>(*gn_src<T>(a, n, col, CP0, (size_t)p, dummy), f);
+      if (cnt == 0) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+        for (int e = 0; e < EPC; ++e) pv[e] = f[e];
       }
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { rs[pl * C + col * EPC + e] = sm[e]; rq[pl * C + col * EPC + e] = sq[e]; }
+      for (int e = 0; e < EPC; ++e) { const float d = f[e] - pv[e]; sm[e] += d; sq[e] += d * d; }
+      ++cnt;
+    }
+    const float ic = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      rs[pl * C + col * EPC + e] = pv[e] + sm[e] * ic;
+      rq[pl * C + col * EPC + e] = fmaxf(sq[e] - sm[e] * sm[e] * ic, 0.f);
     }
   }
   __syncthreads();
   const int cpg = C / a.groups;
   for (int g = t; g < a.groups; g += 256) {
-    float S = 0.f, Q = 0.f;
-    for (int l = 0; l < PL; ++l)
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += rs[l * C + c]; Q += rq[l * C + c]; }
-    float* w = a.ws + (((size_t)n * a.splits + s) * a.groups + g) * 2;
-    w[0] = S; w[1] = Q;
+    GnMerge M;
+    for (int l = 0; l < PL; ++l) {
+      const int left = p1 - p0 - l;
+      const float cl = left > 0 ? (float)((left + PL - 1) / PL) : 0.f;      // pixels pixel-lane l walked
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) M.add(cl, rs[l * C + c], rq[l * C + c]);
+    }
+    const GnAcc A = M.result();
+    reinterpret_cast<float2*>(a.ws)[((size_t)n * a.splits + s) * a.groups + g] = float2{A.mean, A.m2};
   }
 }
 
 // Large samples with producer statistics: fold the sample's quad records (parts x C/4 of them; 512 parts for a 256x256
-// image) into ONE (sum, sumsq) record per group in ws, in a fixed order, so that gn_apply_kernel's workgroups do not each
-// walk the whole record set.  One workgroup per sample; replaces gn_stats_kernel's sweep of the tensor.
+// image) into ONE (mean, M2) record per group in ws, in a fixed order, so that the normalise sweep's workgroups do not each
+// walk the whole record set.  One workgroup per sample; replaces gn_stats_kernel's sweep of the tensor.  A lane walks its share
+// of a quad's parts once, with sums shifted by the first part's mean (equal counts: no division per record).
 __global__ __launch_bounds__(256) void gn_qfold_kernel(const GnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [rows][CQ] float2
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [rows][CQ] x (n, mean, M2)
   const int C = a.C0, CQ = C >> 2, n = blockIdx.x, t = threadIdx.x;
   const int cols = CQ < 256 ? CQ : 256, rows = 256 / cols;
   const int ns = a.map0 ? a.map0[n] : n;
   const float2* w = reinterpret_cast<const float2*>(a.qstats) + (size_t)ns * a.qparts * CQ;
-  float2* r2 = reinterpret_cast<float2*>(red);
+  const float nq = 4.0f * (float)a.HW / (float)a.qparts;
   const int r = t / cols, c = t - r * cols;
   if (r < rows)
     for (int q = c; q < CQ; q += cols) {
-      float S = 0.f, Q = 0.f;
-      for (int p = r; p < a.qparts; p += rows) { const float2 v = w[(size_t)p * CQ + q]; S += v.x; Q += v.y; }
-      r2[r * CQ + q] = float2{S, Q};
+      float cnt = 0.f, piv = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int p = r; p < a.qparts; p += rows) {
+        const float2 v = w[(size_t)p * CQ + q];
+        if (cnt == 0.f) piv = v.x;
+        const float d = v.x - piv;
+        s1 += d; s3 += d * d; s2 += v.y; cnt += 1.f;
+      }
+      const float ic = cnt > 0.f ? 1.0f / cnt : 0.f;
+      red[(r * CQ + q) * 3] = cnt * nq;
+      red[(r * CQ + q) * 3 + 1] = piv + s1 * ic;
+      red[(r * CQ + q) * 3 + 2] = s2 + nq * fmaxf(s3 - s1 * s1 * ic, 0.f);
     }
   __syncthreads();
   const int qpg = (C / a.groups) >> 2;
   for (int g = t; g < a.groups; g += 256) {
-    float S = 0.f, Q = 0.f;
+    GnMerge M;
     for (int rr = 0; rr < rows; ++rr)
-      for (int q = g * qpg; q < (g + 1) * qpg; ++q) { const float2 v = r2[rr * CQ + q]; S += v.x; Q += v.y; }
-    float* o = a.ws + ((size_t)n * a.groups + g) * 2;
-    o[0] = S; o[1] = Q;
+      for (int q = g * qpg; q < (g + 1) * qpg; ++q) M.add(red[(rr * CQ + q) * 3], red[(rr * CQ + q) * 3 + 1], red[(rr * CQ + q) * 3 + 2]);
+    const GnAcc A = M.result();
+    reinterpret_cast<float2*>(a.ws)[(size_t)n * a.groups + g] = float2{A.mean, A.m2};
   }
 }
 
@@ -114,18 +200,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   const int t = threadIdx.x, n = blockIdx.x / a.splits, s = blockIdx.x % a.splits;
   const int cpg = C / a.groups;
   for (int g = t; g < a.groups; g += 256) {
-    float S = 0.f, Q = 0.f;
-    for (int k = 0; k < a.wsplits; ++k) {
-      const float* w = a.ws + (((size_t)n * a.wsplits + k) * a.groups + g) * 2;
-      S += w[0]; Q += w[1];
-    }
-    const float cnt = (float)cpg * (float)a.HW;
-    const float mean = S / cnt;
-    const float var = fmaxf(Q / cnt - mean * mean, 0.f);
-    st[g] = mean; st[a.groups + g] = rsqrtf(var + a.eps);
+    const GnAcc A = gn_fold_ws(a, n, g, cpg);
+    st[g] = A.mean; st[a.groups + g] = rsqrtf(A.var() + a.eps);
   }
   __syncthreads();
-  const int p0 = (int)((long long)a.HW * s / a.splits), p1 = (int)((long long)a.HW * (s + 1) / a.splits);
+  const int p0 = gn_split_lo(a.HW, s, a.splits), p1 = gn_split_lo(a.HW, s + 1, a.splits);
   const int tc = t % TPR, pl = t / TPR;
   int dummy = 0;
   for (int pass = 0; pass < npass; ++pass) {
@@ -167,8 +246,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 // The group statistics are folded in gn_image_kernel's order (parts outer, quads inner), so the two kernels agree bit for bit.
 template <typename T, bool NT>
 __global__ __launch_bounds__(256) void gn_span_kernel(const GnArgs a, const int spans) {
-  constexpr int EPC = Elem<T>::EPC, U = 4, RMAX = 8;             // RMAX x 256 quad records per sample at most (host check)
-  extern __shared__ __attribute__((aligned(16))) float st[];    // mean[groups], rstd[groups], then the sample's quad records
+  constexpr int EPC = Elem<T>::EPC, U = 4, RMAX = 8;             // RMAX x 256 records per sample at most (host check)
+  extern __shared__ __attribute__((aligned(16))) float st[];    // mean[groups], rstd[groups], then the sample's records
   const int t = threadIdx.x, n = blockIdx.x / spans, sp = blockIdx.x - n * spans;
   const int C = a.C0, CP = C / EPC;
   const int ns = a.map0 ? a.map0[n] : n;
@@ -194,18 +273,15 @@ __global__ __launch_bounds__(256) void gn_span_kernel(const GnArgs a, const int 
   for (int k = 0; k < RMAX; ++k) if (t + k * 256 < R) rec[t + k * 256] = rv[k];
   __syncthreads();
   for (int g = t; g < a.groups; g += 256) {
-    float S = 0.f, Q = 0.f;
-    if (a.qstats) {                                              // gn_image_kernel's order: parts outer, the group's quads inner
-      const int qpg = cpg >> 2, CQ = C >> 2;
-      for (int part = 0; part < a.qparts; ++part)
-        for (int q = 0; q < qpg; ++q) { const float2 v = rec[part * CQ + g * qpg + q]; S += v.x; Q += v.y; }
-    } else {
-      for (int k = 0; k < a.wsplits; ++k) { const float2 v = rec[k * a.groups + g]; S += v.x; Q += v.y; }
-    }
-    const float cnt = (float)cpg * (float)a.HW;
-    const float mean = S / cnt;
-    st[g] = mean;
-    st[a.groups + g] = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + a.eps);
+    GnAcc A;
+    if (a.qstats) A = gn_fold_rec(rec, a.qparts, C >> 2, g, cpg >> 2, 4.0f * (float)a.HW / (float)a.qparts);
+    else
+      for (int k = 0; k < a.wsplits; ++k) {
+        const float2 v = rec[k * a.groups + g];
+        A.add((float)cpg * (float)(gn_split_lo(a.HW, k + 1, a.wsplits) - gn_split_lo(a.HW, k, a.wsplits)), v.x, v.y);
+      }
+    st[g] = A.mean;
+    st[a.groups + g] = rsqrtf(A.var() + a.eps);
   }
   __syncthreads();
   float sc[EPC], sh[EPC];
@@ -240,7 +316,7 @@ template <typename T>
 __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int NT = 512, UNR = 4;
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][PL][C] partial sums, then mean[groups] / rstd[groups]
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][PL][C] per-thread mean / M2, then mean[groups] / rstd[groups]
   const int C = a.C0 + a.C1;
   const int CP = C / EPC, CP0 = a.C0 / EPC;
   int TPR = 1; while (TPR < CP) TPR <<= 1;                      // CP <= 512 (host check)
@@ -251,52 +327,64 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
   int dummy = 0;
   const chunk16* src = on ? gn_src<T>(a, n, tc, CP0, 0, dummy) : nullptr;
   const size_t pstride = (size_t)(tc < CP0 ? a.C0 : a.C1) * sizeof(T) / 16;      // chunks per pixel row of the lane's source
-  float sm[EPC], sq[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+  float* rs = red; float* rq = red + PL * C;
   if (on && !a.qstats) {
+    float pv[EPC], sm[EPC], sq[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { pv[e] = 0.f; sm[e] = 0.f; sq[e] = 0.f; }
+    bool have = false;                                                   // the lane's pivot: its first pixel, taken from the first fetch
     int p = pl;
     for (; p + (UNR - 1) * PL < a.HW; p += UNR * PL) {
       chunk16 c[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) c[u] = src[(size_t)(p + u * PL) * pstride];
+      if (!have) { chunk_to_f<T>(c[0], pv); have = true; }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         float f[EPC];
         chunk_to_f<T>(c[u], f);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+        for (int e = 0; e < EPC; ++e) { const float d = f[e] - pv[e]; sm[e] += d; sq[e] += d * d; }
       }
     }
     for (; p < a.HW; p += PL) {
       float f[EPC];
       chunk_to_f<T>(src[(size_t)p * pstride], f);
+      if (!have) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+        for (int e = 0; e < EPC; ++e) pv[e] = f[e];
+        have = true;
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { const float d = f[e] - pv[e]; sm[e] += d; sq[e] += d * d; }
     }
-  }
-  float* rs = red; float* rq = red + PL * C;
-  if (on && !a.qstats) {
+    const int left = a.HW - pl;
+    const float ic = left > 0 ? 1.0f / (float)((left + PL - 1) / PL) : 0.f;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { rs[pl * C + tc * EPC + e] = sm[e]; rq[pl * C + tc * EPC + e] = sq[e]; }
+    for (int e = 0; e < EPC; ++e) {
+      rs[pl * C + tc * EPC + e] = pv[e] + sm[e] * ic;
+      rq[pl * C + tc * EPC + e] = fmaxf(sq[e] - sm[e] * sm[e] * ic, 0.f);
+    }
   }
   __syncthreads();
   const int cpg = C / a.groups;
   float mean_g = 0.f, rstd_g = 0.f;
   if (t < a.groups) {                                            // groups <= 512 (host check)
-    float S = 0.f, Q = 0.f;
+    GnAcc A;
     if (a.qstats) {                                              // the producer's quad records, parts in fixed order
-      const int ns = a.map0 ? a.map0[n] : n, qpg = cpg >> 2, CQ = C >> 2;
-      for (int part = 0; part < a.qparts; ++part) {
-        const float2* w = reinterpret_cast<const float2*>(a.qstats) + ((size_t)ns * a.qparts + part) * CQ + t * qpg;
-        for (int q = 0; q < qpg; ++q) { const float2 v = w[q]; S += v.x; Q += v.y; }
+      const int ns = a.map0 ? a.map0[n] : n;
+      A = gn_fold_rec(reinterpret_cast<const float2*>(a.qstats) + (size_t)ns * a.qparts * (C >> 2), a.qparts, C >> 2, t, cpg >> 2, 4.0f * (float)a.HW / (float)a.qparts);
+    } else {
+      GnMerge M;
+      for (int l = 0; l < PL; ++l) {
+        const int left = a.HW - l;
+        const float cl = left > 0 ? (float)((left + PL - 1) / PL) : 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) M.add(cl, rs[l * C + c], rq[l * C + c]);
       }
-    } else
-    for (int l = 0; l < PL; ++l)
-      for (int c = t * cpg; c < (t + 1) * cpg; ++c) { S += rs[l * C + c]; Q += rq[l * C + c]; }
-    const float cnt = (float)cpg * (float)a.HW;
-    mean_g = S / cnt;
-    rstd_g = rsqrtf(fmaxf(Q / cnt - mean_g * mean_g, 0.f) + a.eps);
+      A = M.result();
+    }
+    mean_g = A.mean;
+    rstd_g = rsqrtf(A.var() + a.eps);
   }
   __syncthreads();
   if (t < a.groups) { red[t] = mean_g; red[a.groups + t] = rstd_g; }
@@ -334,14 +422,15 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
 }
 
 // Tiny samples (4x4 / 8x8 levels: <= 32 chunks per lane): one WAVE per sample, four samples per workgroup.  The sample
-// is read once into registers, the statistics are folded with xor-shuffles and a wave-private LDS strip, and the
-// normalised chunks are written straight from the registers: no workgroup barrier, no second read.  (The
-// one-workgroup-per-sample kernel ran these 16-32 KiB samples at 1.9 TB/s: three barrier-separated phases of 512 threads
-// per 16 KiB.)  Summation order depends on (HW, C) only.
+// is read once into registers, the statistics (shifted sums per channel, pivot = the channel's value at pixel 0) are folded
+// with xor-shuffles and a wave-private LDS strip, and the normalised chunks are written straight from the registers: no
+// workgroup barrier, no second read.
+// (The one-workgroup-per-sample kernel ran these 16-32 KiB samples at 1.9 TB/s: three barrier-separated phases of 512
+// threads per 16 KiB.)  Summation order depends on (HW, C) only.
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void gn_wave_kernel(const GnArgs a, const int n_total) {
   constexpr int EPC = Elem<T>::EPC;
-  extern __shared__ __attribute__((aligned(16))) float red[];   // per wave: sum[C], sumsq[C], mean[groups], rstd[groups]
+  extern __shared__ __attribute__((aligned(16))) float red[];   // per wave: sum[C] (then centred sumsq[C]), mean[groups], rstd[groups]
   const int C = a.C0 + a.C1;
   const int CP = C / EPC, CP0 = a.C0 / EPC;
   int TPR = 1; while (TPR < CP) TPR <<= 1;                      // CP <= 64 (host check)
@@ -361,39 +450,54 @@ __global__ __launch_bounds__(256) void gn_wave_kernel(const GnArgs a, const int 
     const int p = pl + i * PL;
     c[i] = (on && p < a.HW) ? src[(size_t)p * pstride] : chunk16{0u, 0u, 0u, 0u};
   }
-  float sm[EPC], sq[EPC];
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int cpg = C / a.groups;
+  // one pass over the registers with SHIFTED sums: the pivot of a channel is its value at pixel 0, which lane tc (pixel lane 0 of
+  // the column) holds in its first chunk — one shuffle per channel of the chunk; padding chunks are skipped, so every lane of a
+  // column sums (v - pivot) and (v - pivot)^2 of real pixels only and the pixel lanes add up linearly
+  float pv[EPC], sm[EPC], sq[EPC];
+  {
+    float f0[EPC];
+    chunk_to_f<T>(c[0], f0);
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+    for (int e = 0; e < EPC; ++e) { pv[e] = __shfl(f0[e], tc, 64); sm[e] = 0.f; sq[e] = 0.f; }
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
+    if (pl + i * PL >= a.HW) continue;
     float f[EPC];
     chunk_to_f<T>(c[i], f);
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+    for (int e = 0; e < EPC; ++e) { const float d = f[e] - pv[e]; sm[e] += d; sq[e] += d * d; }
   }
   for (int o = TPR; o < 64; o <<= 1) {                          // over the pixel lanes of the wave
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { sm[e] += __shfl_xor(sm[e], o, 64); sq[e] += __shfl_xor(sq[e], o, 64); }
   }
-  if (on && pl == 0) {
+  if (on && pl == 0) {                                          // per channel: mean and M2 over the sample's HW pixels
+    const float ihw = 1.0f / (float)a.HW;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { wred[tc * EPC + e] = sm[e]; wred[C + tc * EPC + e] = sq[e]; }
+    for (int e = 0; e < EPC; ++e) {
+      wred[tc * EPC + e] = pv[e] + sm[e] * ihw;
+      wred[C + tc * EPC + e] = fmaxf(sq[e] - sm[e] * sm[e] * ihw, 0.f);
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int cpg = C / a.groups;
-  for (int g = lane; g < a.groups; g += 64) {
-    float S = 0.f, Q = 0.f;
-    for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) { S += wred[ch]; Q += wred[C + ch]; }
-    const float cnt = (float)cpg * (float)a.HW;
-    const float mean = S / cnt;
+  wave_sync();
+  for (int g = lane; g < a.groups; g += 64) {                   // equal counts: average of the channel means, M2 merged around it
+    float s1 = 0.f, s2 = 0.f;
+    for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) { s1 += wred[ch]; s2 += wred[C + ch]; }
+    const float mean = s1 / (float)cpg;
+    float s3 = 0.f;
+    for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) { const float d = wred[ch] - mean; s3 += d * d; }
+    const float var = (s2 + (float)a.HW * s3) / ((float)cpg * (float)a.HW);
     wred[2 * C + g] = mean;
-    wred[2 * C + a.groups + g] = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + a.eps);
+    wred[2 * C + a.groups + g] = rsqrtf(fmaxf(var, 0.f) + a.eps);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_sync();
   if (!on) return;
   float sc[EPC], sh[EPC];
 #pragma unroll
@@ -437,15 +541,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs a, float*
   const int C = a.C0 + a.C1, n = blockIdx.x, t = threadIdx.x;
   const int cpg = C / a.groups;
   for (int g = t; g < a.groups; g += 256) {
-    float S = 0.f, Q = 0.f;
-    for (int k = 0; k < a.splits; ++k) {
-      const float* w = a.ws + (((size_t)n * a.splits + k) * a.groups + g) * 2;
-      S += w[0]; Q += w[1];
-    }
-    const float cnt = (float)cpg * (float)a.HW;
-    const float mean = S / cnt;
-    const float var = fmaxf(Q / cnt - mean * mean, 0.f);
-    st[g] = mean; st[64 + g] = rsqrtf(var + a.eps);
+    const GnAcc A = gn_fold_ws(a, n, g, cpg);
+    st[g] = A.mean; st[64 + g] = rsqrtf(A.var() + a.eps);
   }
   __syncthreads();
   for (int c = t; c < C; c += 256) {
@@ -463,17 +560,11 @@ __global__ __launch_bounds__(256) void gn_qaffine_kernel(const GnArgs a, float* 
   extern __shared__ __attribute__((aligned(16))) float st[];    // mean[groups], rstd[groups]
   const int C = a.C0, n = blockIdx.x, t = threadIdx.x;
   const int ns = a.map0 ? a.map0[n] : n;
-  const int cpg = C / a.groups, qpg = cpg >> 2, CQ = C >> 2;
+  const int cpg = C / a.groups;
   for (int g = t; g < a.groups; g += 256) {
-    float S = 0.f, Q = 0.f;
-    for (int part = 0; part < a.qparts; ++part) {
-      const float2* w = reinterpret_cast<const float2*>(a.qstats) + ((size_t)ns * a.qparts + part) * CQ + g * qpg;
-      for (int q = 0; q < qpg; ++q) { const float2 v = w[q]; S += v.x; Q += v.y; }
-    }
-    const float cnt = (float)cpg * (float)a.HW;
-    const float mean = S / cnt;
-    st[g] = mean;
-    st[a.groups + g] = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + a.eps);
+    const GnAcc A = gn_fold_rec(reinterpret_cast<const float2*>(a.qstats) + (size_t)ns * a.qparts * (C >> 2), a.qparts, C >> 2, g, cpg >> 2, 4.0f * (float)a.HW / (float)a.qparts);
+    st[g] = A.mean;
+    st[a.groups + g] = rsqrtf(A.var() + a.eps);
   }
   __syncthreads();
   for (int c = t; c < C; c += 256) {
@@ -515,8 +606,8 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   a.out_dtype = p->out_dtype; a.eps = p->eps;
   a.qstats = nullptr; a.qparts = 0; a.wsplits = p->splits;
   if (p->qstats) {
-    DC_REQUIRE(C1 == 0 && p->qparts > 0 && (C / p->groups) % 4 == 0 && ((uintptr_t)p->qstats & 7) == 0, DC_ERR_ARG,
-               "dc_groupnorm: qstats needs one source, qparts > 0 and (C/groups) %% 4 == 0 (C=%d groups=%d C1=%d)", C, p->groups, C1);
+    DC_REQUIRE(C1 == 0 && p->qparts > 0 && p->HW % p->qparts == 0 && (C / p->groups) % 4 == 0 && ((uintptr_t)p->qstats & 7) == 0, DC_ERR_ARG,
+               "dc_groupnorm: qstats needs one source, qparts > 0 dividing HW and (C/groups) %% 4 == 0 (C=%d groups=%d C1=%d HW=%d qparts=%d)", C, p->groups, C1, p->HW, p->qparts);
   }
   const int CP = C / epc;
   int TPR = 1; while (TPR < CP && TPR < 256) TPR <<= 1;
@@ -582,7 +673,7 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
     const bool fold = qsplit || (long long)p->qparts * (C >> 2) > 8 * 256;
     if (fold) {                                // many quad records per sample: fold them once per sample, not once per span
       const int CQ = C >> 2, cols = CQ < 256 ? CQ : 256;
-      hipLaunchKernelGGL(gn_qfold_kernel, dim3((unsigned)p->n), blk, (size_t)(256 / cols) * CQ * sizeof(float2), s, a);
+      hipLaunchKernelGGL(gn_qfold_kernel, dim3((unsigned)p->n), blk, (size_t)(256 / cols) * CQ * 3 * sizeof(float), s, a);
       a.qstats = nullptr; a.wsplits = 1;
     }
     const int spans = (int)(chunks / 1024);
@@ -612,7 +703,7 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   if (!sweep) {
     a.qstats = p->qstats; a.qparts = p->qparts;
     const int CQ = C >> 2, cols = CQ < 256 ? CQ : 256;
-    hipLaunchKernelGGL(gn_qfold_kernel, dim3((unsigned)p->n), blk, (size_t)(256 / cols) * CQ * sizeof(float2), s, a);
+    hipLaunchKernelGGL(gn_qfold_kernel, dim3((unsigned)p->n), blk, (size_t)(256 / cols) * CQ * 3 * sizeof(float), s, a);
     a.qstats = nullptr; a.wsplits = 1;
   }
   if (p->dtype == DC_F32) {

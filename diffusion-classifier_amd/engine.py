@@ -153,7 +153,7 @@ class PlanBuilder:
             assert src1.dt == src0.dt and (src1.H, src1.W) == (src0.H, src0.W)
         qs = None
         if qstats and L.lib().dc_igemm_qstats_parts is not None:
-            # the conv also writes (sum, sumsq) per (sample, part, channel quad) of its output: the GroupNorm that consumes the
+            # the conv also writes (mean, M2) per (sample, part, channel quad) of its output: the GroupNorm that consumes the
             # tensor then streams it once (read + write) instead of sweeping it twice
             fake = 1 << 20
             probe = L.IgemmParams(**{k: (fake if isinstance(v, TRef) else v) for k, v in f.items() if v is not None})

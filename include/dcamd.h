@@ -120,10 +120,11 @@ typedef struct {
    * when packing (row taps: a=0 -> (k0 | k1+k2), a=1 -> (k0+k1 | k2); columns alike).  4/9 of the MACs, same result up
    * to the rounding of the summed weights. */
   int32_t up4;
-  /* quad statistics of the OUTPUT for a following GroupNorm (dc_groupnorm_params.qstats): per output sample n, per part
-   * and per quad of 4 consecutive output channels the (sum, sum of squares) of the output values (fp32, before the rounding to out_dtype),
-   * qstats[((n * qparts + part) * (Cout/4) + quad) * 2 + (0 | 1)], qparts = dc_igemm_qstats_parts().  The GroupNorm then
-   * streams the tensor once instead of reading it twice.  NULL otherwise. */
+  /* quad statistics of the OUTPUT for a following GroupNorm (dc_groupnorm_params.qstats): per output sample n, per part (a run
+   * of HW / qparts pixels) and per quad q of 4 consecutive output channels the mean and the centred second moment
+   * M2 = sum (v - mean)^2 of the quad's 4 * HW / qparts output values (fp32, before the rounding to out_dtype; shifted sums, no
+   * cancellation for |mean| >> std): qstats[((n * qparts + part) * (Cout/4) + q) * 2 + (0 = mean | 1 = M2)],
+   * qparts = dc_igemm_qstats_parts().  The GroupNorm then streams the tensor once instead of reading it twice.  NULL otherwise. */
   float* qstats;
 } dc_igemm_params;
 int dc_igemm(const dc_igemm_params* p, dc_stream s);
@@ -171,7 +172,8 @@ int dc_pack_weights_geglu(const float* w, const float* bias, int32_t n_half, int
 int dc_fold_layernorm_bias(const float* w, const float* bias, const float* ln_beta, int32_t cout, int32_t K, float* out_bias, dc_stream s);
 
 /* ---------------------------------------------------------------- norms ---------- */
-/* GroupNorm over (C/groups)*HW per (sample, group), NHWC, fp32 statistics, optional SiLU.
+/* GroupNorm over (C/groups)*HW per (sample, group), NHWC, optional SiLU.  fp32 statistics carried as (mean, M2) sets
+ * merged with Chan's update in a fixed order (shifted per-thread sums): no sum / sum-of-squares cancellation.
  * ws: float workspace >= dc_groupnorm_ws_floats(n, groups, splits). */
 typedef struct {
   const void* x; const int32_t* map0;   /* source 0: [*, HW, C] ; map: sample -> source sample or NULL */
@@ -183,9 +185,9 @@ typedef struct {
    * out_scale[n][C+C1] = rstd*gamma and out_shift = beta - mean*rstd*gamma, which dc_igemm applies on the
    * fly (gn_scale / gn_shift) — the normalised tensor is then never written to HBM. */
   float* out_scale; float* out_shift;
-  /* statistics already formed by the producer of x (dc_igemm_params.qstats; qparts parts per sample): single source
-   * (C1 == 0), (C/groups) a multiple of 4.  The statistics sweep is skipped; in statistics-only mode the tensor is not
-   * read at all (x is then only the sample count's witness).  NULL / 0 otherwise. */
+  /* statistics already formed by the producer of x (dc_igemm_params.qstats; qparts parts per sample, qparts divides HW):
+   * single source (C1 == 0), (C/groups) a multiple of 4.  The statistics sweep is skipped; in statistics-only mode the tensor
+   * is not read at all (x is then only the sample count's witness).  NULL / 0 otherwise. */
   const float* qstats; int32_t qparts, pad_;
 } dc_groupnorm_params;
 int dc_groupnorm(const dc_groupnorm_params* p, dc_stream s);

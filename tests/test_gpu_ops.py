@@ -343,6 +343,67 @@ def test_groupnorm(dt, shape):
     assert err < (2e-4 if dt == L.DC_F32 else 6e-2), err     # outputs are O(1..8); bf16 rounding 2^-8 relative
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 256, 0), (2, 64, 128, 128), (3, 1024, 128, 0), (2, 4096, 128, 0), (2, 65536, 64, 0)])
+def test_groupnorm_with_large_offsets_f32(shape):
+    """|mean| >> std: group means of ~1e3 standard deviations.  The sum / sum-of-squares
+    form loses the variance to cancellation there (fp32: relative error ~1e-7 * mean^2 / var = 10 %); the (mean, M2) form with
+    shifted sums must stay at torch's own accuracy.  Paths: one wave per sample, one workgroup per sample, split sweep, 16 MiB
+    samples."""
+    n, HW, C0, C1 = shape
+    torch.manual_seed(44)
+    Cc = C0 + C1
+    off = (torch.randn(1, 1, 32, 1) * 300 + 1000).expand(1, 1, 32, Cc // 32).reshape(1, 1, Cc)   # one offset of ~1e3 std per GROUP
+    xcat = torch.randn(n, HW, Cc) + off
+    gamma, beta = torch.randn(Cc), torch.randn(Cc)
+    ref = F.silu(F.group_norm(xcat.double().permute(0, 2, 1).reshape(n, Cc, HW), 32, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 1).float()
+    lib = L.lib()
+    splits = lib.dc_groupnorm_splits(n, HW, Cc)
+    ws = torch.zeros(lib.dc_groupnorm_ws_floats(n, 32, splits), device=DEV)
+    x0d = xcat[..., :C0].contiguous().to(DEV)
+    x1d = xcat[..., C0:].contiguous().to(DEV) if C1 else None
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    y = torch.full((n, HW, Cc), float("nan"), device=DEV)
+    p = L.GroupnormParams(x=ptr(x0d), x1=ptr(x1d), y=ptr(y), dtype=L.DC_F32, out_dtype=L.DC_F32, n=n, HW=HW, C=C0, C1=C1, groups=32, silu=1,
+                          splits=splits, eps=1e-5, gamma=ptr(gd), beta=ptr(bd), ws=ptr(ws))
+    L.check(lib.dc_groupnorm(p, L.stream_ptr()), "gn")
+    torch.cuda.synchronize()
+    err = (y.cpu() - ref).abs().max().item()
+    t32 = F.silu(F.group_norm(xcat.permute(0, 2, 1).reshape(n, Cc, HW), 32, gamma, beta, 1e-5)).permute(0, 2, 1)
+    err_torch = (t32 - ref).abs().max().item()                       # torch's own fp32 kernel against the fp64 reference
+    assert err < max(4 * err_torch, 2e-4), (err, err_torch)
+
+
+def test_groupnorm_from_producer_statistics_with_large_offsets_f32():
+    """The conv's channel records at a large output offset (bias ~ 1e3 x the output's spread): GroupNorm from the records must match
+    the fp64 GroupNorm of the stored tensor."""
+    torch.manual_seed(45)
+    n, H, W, C0, Cout = 2, 32, 32, 32, 128
+    x0 = torch.randn(n, C0, H, W)
+    w = torch.randn(Cout, C0, 3, 3) / (3 * C0 ** 0.5) * 0.05           # small spread ...
+    b = (torch.randn(32, 1) * 20 + 60).expand(32, Cout // 32).reshape(Cout).contiguous()   # ... on a large offset per GROUP
+    lib = L.lib()
+    a0, bd, Wp = nhwc(x0, L.DC_F32), b.to(DEV), E.pack_conv3x3(w, L.DC_F32, DEV)
+    out = torch.empty(n, H, W, Cout, device=DEV)
+    kw = dict(dtype=L.DC_F32, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=C0, W=ptr(Wp),
+              Cout=Cout, tile_n=128, bias=ptr(bd), out=ptr(out), out_dtype=L.DC_F32, out_ld=Cout)
+    parts = lib.dc_igemm_qstats_parts(L.IgemmParams(**kw))
+    qs = torch.zeros(n, parts, Cout // 4, 2, device=DEV)
+    run_igemm(qstats=ptr(qs), **kw)
+    gamma, beta = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
+    splits = lib.dc_groupnorm_splits(n, H * W, Cout)
+    ws = torch.zeros(lib.dc_groupnorm_ws_floats(n, 32, splits), device=DEV)
+    y = torch.empty_like(out)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(x=ptr(out), y=ptr(y), dtype=L.DC_F32, out_dtype=L.DC_F32, n=n, HW=H * W, C=Cout, C1=0, groups=32,
+                                               silu=0, splits=splits, eps=1e-5, gamma=ptr(gamma), beta=ptr(beta), ws=ptr(ws), qstats=ptr(qs),
+                                               qparts=parts), L.stream_ptr()), "gn")
+    torch.cuda.synchronize()
+    o64 = out.double().permute(0, 3, 1, 2)
+    ref = F.group_norm(o64, 32, gamma.double(), beta.double(), 1e-5).permute(0, 2, 3, 1).float()
+    t32 = F.group_norm(out.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5).permute(0, 2, 3, 1)
+    err, err_torch = (y - ref).abs().max().item(), (t32 - ref).abs().max().item()
+    assert err < max(4 * err_torch, 2e-4), (err, err_torch)
+
+
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
 @pytest.mark.parametrize("C_", [64, 256, 768, 1024])
 def test_layernorm_plain_and_adaln(dt, C_):
@@ -584,6 +645,13 @@ def test_conv3x3_with_fused_groupnorm_prologue(dt, concat):
     assert lib.dc_igemm_gn_fusable(p) == 0 and lib.dc_igemm(p, L.stream_ptr()) == -6
 
 
+def _merge_quad_records(qs, nq):
+    """(mean, M2) records [n, parts, C/4, 2], each over nq values -> per-quad mean and M2 over the whole sample (Chan's merge)."""
+    mean = qs[..., 0].double().mean(1)
+    m2 = qs[..., 1].double().sum(1) + nq * ((qs[..., 0].double() - mean[:, None]) ** 2).sum(1)
+    return mean, m2
+
+
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
 @pytest.mark.parametrize("shape", [(3, 32, 32, 128, 3), (2, 16, 16, 256, 12), (2, 64, 32, 128, 4)])
 def test_thin_conv_with_groupnorm_from_quad_statistics(dt, shape):
@@ -683,14 +751,16 @@ def test_conv3x3_quad_statistics_feed_groupnorm(dt, shape):
     run_igemm(**dict(kw, out=ptr(out2)))
     assert torch.equal(out, out2)                                   # the statistics do not touch the output
     of = out.float()
-    quads = of.reshape(n, H * W, Cout // 4, 4)
-    s_ref, q_ref = quads.sum((1, 3)), (quads.double() ** 2).sum((1, 3)).float()
-    got = qs.sum(1)
-    assert torch.isfinite(qs).all()
-    # the sums are formed from the fp32 accumulators BEFORE the rounding to the storage type: for 16-bit outputs they differ
-    # from the sums over the stored tensor by the (zero-mean) rounding errors, ~2^-9 / sqrt(count) relative
-    assert (got[..., 0] - s_ref).abs().max().item() < 2e-3 * max(1.0, s_ref.abs().max().item())
-    assert (got[..., 1] - q_ref).abs().max().item() < (1e-4 if dt == L.DC_F32 else 2e-3) * q_ref.abs().max().item()
+    assert torch.isfinite(qs).all() and (qs[..., 1] >= 0).all()
+    # records: per (sample, part, quad) mean and M2 = sum (v - mean)^2 of the quad's 4 * HW / parts values; merged over the parts they
+    # must be the quad's mean and centred second moment over the sample.  They are formed from the fp32 accumulators BEFORE the
+    # rounding to the storage type: for 16-bit outputs they differ from the stored tensor's by the (zero-mean) rounding errors
+    m_got, m2_got = _merge_quad_records(qs, 4 * H * W // parts)
+    px = of.double().reshape(n, H * W, Cout // 4, 4)
+    m_ref = px.mean((1, 3))
+    m2_ref = ((px - m_ref[:, None, :, None]) ** 2).sum((1, 3))
+    assert (m_got - m_ref).abs().max().item() < (1e-5 if dt == L.DC_F32 else 2e-3) * max(1.0, m_ref.abs().max().item())
+    assert ((m2_got - m2_ref).abs() / m2_ref).max().item() < (1e-4 if dt == L.DC_F32 else 1e-2)
     # GroupNorm(+SiLU) from the quad statistics == GroupNorm that sweeps the tensor
     gamma, beta = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
     splits = lib.dc_groupnorm_splits(n, H * W, Cout)
@@ -705,10 +775,12 @@ def test_conv3x3_quad_statistics_feed_groupnorm(dt, shape):
     tol = {L.DC_F32: 2e-5, L.DC_BF16: 1e-2, L.DC_F16: 2e-3}[dt]
     assert maxrel(yb.float(), ref) < tol, maxrel(yb.float(), ref)
     assert maxrel(yb.float(), ya.float()) < tol
-    # refused where the halo kernel does not run (stride 2) and for a GroupNorm whose groups are not whole quads
+    # refused where the halo kernel does not run (stride 2), for a GroupNorm whose groups are not whole quads, and for a part count
+    # that does not divide the sample
     p2 = L.IgemmParams(**dict(kw, stride=2, Hout=H // 2, Wout=W // 2, residual=None, qstats=ptr(qs)))
     assert lib.dc_igemm_qstats_parts(p2) == 0 and lib.dc_igemm(p2, L.stream_ptr()) == -6
     assert lib.dc_groupnorm(L.GroupnormParams(y=ptr(yb), qstats=ptr(qs), qparts=parts, **dict(gk, groups=Cout // 2)), L.stream_ptr()) != 0
+    assert lib.dc_groupnorm(L.GroupnormParams(y=ptr(yb), qstats=ptr(qs), qparts=7, **gk), L.stream_ptr()) != 0
 
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
@@ -750,12 +822,13 @@ def test_upsample_conv_as_four_phases(dt, shape):
     assert lib.dc_igemm_up4_ok(p2) == 0 and lib.dc_igemm(p2, L.stream_ptr()) == -6
     if not halo:
         return
-    quads = out.float().reshape(n, 4 * H * W, Cout // 4, 4)
-    s_ref, q_ref = quads.sum((1, 3)), (quads.double() ** 2).sum((1, 3)).float()
-    tot = qs.sum(1)
     assert torch.isfinite(qs).all()
-    assert (tot[..., 0] - s_ref).abs().max().item() < 2e-3 * max(1.0, s_ref.abs().max().item())
-    assert (tot[..., 1] - q_ref).abs().max().item() < (1e-4 if dt == L.DC_F32 else 2e-3) * q_ref.abs().max().item()
+    m_got, m2_got = _merge_quad_records(qs, 4 * 4 * H * W // parts)
+    px = out.double().reshape(n, 4 * H * W, Cout // 4, 4)
+    m_ref = px.mean((1, 3))
+    m2_ref = ((px - m_ref[:, None, :, None]) ** 2).sum((1, 3))
+    assert (m_got - m_ref).abs().max().item() < (1e-5 if dt == L.DC_F32 else 2e-3) * max(1.0, m_ref.abs().max().item())
+    assert ((m2_got - m2_ref).abs() / m2_ref).max().item() < (1e-4 if dt == L.DC_F32 else 1e-2)
 
 
 @pytest.mark.parametrize("shape", [(5, 10, 50, 50, 3), (3, 6, 7, 3, 2), (2, 100, 9, 9, 1), (4, 1000, 4, 2, 7)])
