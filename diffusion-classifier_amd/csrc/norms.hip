@@ -430,7 +430,7 @@ __global__ __launch_bounds__(512) void gn_image_kernel(const GnArgs a) {
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void gn_wave_kernel(const GnArgs a, const int n_total) {
   constexpr int EPC = Elem<T>::EPC;
-  extern __shared__ __attribute__((aligned(16))) float red[];   // per wave: sum[C] (then centred sumsq[C]), mean[groups], rstd[groups]
+  extern __shared__ __attribute__((aligned(16))) float red[];   // per wave: channel mean[C], channel M2[C], mean[groups], rstd[groups]
   const int C = a.C0 + a.C1;
   const int CP = C / EPC, CP0 = a.C0 / EPC;
   int TPR = 1; while (TPR < CP) TPR <<= 1;                      // CP <= 64 (host check)

@@ -637,7 +637,7 @@ class UNetPlan:
         fuse_gn_out = os.environ.get("DCAMD_NO_GN_OUT_FUSION") is None
         split_skips = os.environ.get("DCAMD_NO_SKIP_SPLIT") is None
         fold_short = os.environ.get("DCAMD_NO_SHORT_FOLD") is None
-        # 3x3 convs also emit the (sum, sumsq) quad statistics of their output, so the GroupNorm that follows streams the
+        # 3x3 convs also emit the (mean, M2) quad statistics of their output, so the GroupNorm that follows streams the
         # tensor once (read + write) instead of twice + write: GroupNorm 8.3 -> ~6 ms per cfg2 step
         use_qs = os.environ.get("DCAMD_NO_QSTATS") is None
         use_up4 = os.environ.get("DCAMD_NO_UP4") is None
