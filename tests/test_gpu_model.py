@@ -49,6 +49,30 @@ def test_small_unet_forward_f32(share):
     assert (got - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
+def test_small_unet_forward_f32_with_large_activation_offsets():
+    """A checkpoint-like failure mode random weights never show: conv biases far larger than the activations' spread, so that every
+    GroupNorm sees groups with |mean| >> std (tens of standard deviations here; the offsets differ per group).  The fp32 path must
+    still sit on the oracle — the sum / sum-of-squares statistics of round 1 lost the variance to cancellation at this point."""
+    kw = dca.small_unet_kwargs()
+    m, o = make_pair(kw, seed=3)
+    G = kw.get("norm_num_groups", 32)
+    with torch.no_grad():
+        torch.manual_seed(4)
+        for n, p in m.named_parameters():
+            if p.dim() == 1 and n.endswith("bias") and (".conv1." in n or ".conv2." in n or "conv_in" in n or ".conv." in n or "conv_shortcut" in n):
+                cpg = max(p.numel() // G, 1)
+                p.add_((torch.randn(p.numel() // cpg, 1) * 8 + 25).expand(-1, cpg).reshape(-1)[: p.numel()])
+    o.load_state_dict(m.state_dict())
+    torch.manual_seed(5)
+    N = 5
+    x, lam, emb = torch.randn(N, 3, 32, 32), torch.tensor([9.0, 2.0, 0.0, -3.0, -9.0]), torch.randn(N, 1, 64)
+    ref = o(x, lam, encoder_hidden_states=emb)
+    m = m.to(DEV)
+    got = m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    assert torch.isfinite(got).all()
+    assert relerr(got, ref) < 5e-5, relerr(got, ref)
+
+
 @pytest.mark.parametrize("dtname,tol", [("bf16", 1.5e-2), ("f16", 2.5e-3)])
 def test_small_unet_forward_lowp(dtname, tol):
     kw = dca.small_unet_kwargs()
