@@ -477,6 +477,39 @@ def test_attention_long_sequences_flash(dt, Ld):
     assert (got - ref).abs().max().item() < (2e-2 if dt == L.DC_BF16 else 3e-3)   # P and O rounded to 16 bit
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("Ld", [(16, 64), (64, 32), (128, 64), (256, 64), (1024, 64), (100, 16)])
+def test_attention_with_large_logits(dt, Ld):
+    """Trained attention layers produce peaked rows: logits of +-60 and more after the 1/sqrt(d) scale (random weights stay near +-3).
+    exp() of an unshifted logit overflows fp32 at 88 and f16 at 11: every kernel (one wave per pair, whole-sequence, flash, the
+    fp32 fallback) must subtract the row maximum — the result has to be finite and equal to torch's, rows that are one-hot included."""
+    Lq, d = Ld
+    if dt == L.DC_F32 and Lq > 256:
+        pytest.skip("fp32 attention is the parity path of the UNets: short sequences only")
+    torch.manual_seed(26)
+    n, heads = 2, 2
+    Cc = heads * d
+    q = lambda t: t.to(TD[dt]).float()
+    qkv = torch.randn(n, Lq, 3 * Cc)
+    qkv[..., :2 * Cc] *= 5.0                        # q.k / sqrt(d) ~ N(0, 25^2): row maxima of 60-100
+    qkv = q(qkv)
+    sh = lambda z: z.view(n, Lq, heads, d).transpose(1, 2)
+    logits = sh(qkv[..., :Cc]) @ sh(qkv[..., Cc:2 * Cc]).transpose(-1, -2) * d ** -0.5
+    assert logits.amax(-1).max().item() > 60
+    ref = F.scaled_dot_product_attention(sh(qkv[..., :Cc]).double(), sh(qkv[..., Cc:2 * Cc]).double(), sh(qkv[..., 2 * Cc:]).double())
+    ref = ref.transpose(1, 2).reshape(n, Lq, Cc).float()
+    qd = qkv.to(TD[dt]).to(DEV)
+    out = torch.full((n, Lq, Cc), float("nan"), dtype=TD[dt], device=DEV)
+    es = 4 if dt == L.DC_F32 else 2
+    p = L.AttentionParams(q=qd.data_ptr(), k=qd.data_ptr() + Cc * es, v=qd.data_ptr() + 2 * Cc * es, out=ptr(out), dtype=dt,
+                          n=n, L=Lq, heads=heads, d=d, ld_qkv=3 * Cc, ld_out=Cc, scale=d ** -0.5)
+    L.check(L.lib().dc_attention(p, L.stream_ptr()), "attn")
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    # a logit error of eps_T * |logit| (the q.k products are exact in fp32, the 16-bit kernels round P and O) moves a weight by that factor
+    assert (got - ref).abs().max().item() < {L.DC_F32: 2e-4, L.DC_BF16: 4e-2, L.DC_F16: 6e-3}[dt]
+
+
 def test_attention_f32_long_sequence_is_refused_loudly():
     x = torch.zeros(1, device=DEV)
     p = L.AttentionParams(q=ptr(x), k=ptr(x), v=ptr(x), out=ptr(x), dtype=0, n=1, L=4096, heads=1, d=64, ld_qkv=192, ld_out=64, scale=1)
