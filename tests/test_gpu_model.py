@@ -49,6 +49,20 @@ def test_small_unet_forward_f32(share):
     assert (got - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("size", [24, 20])
+def test_small_unet_forward_f32_non_power_of_two_images(size):
+    """Image extents the halo kernels do not take (they want powers of two): every conv falls to the tap-gather GEMM, attention runs on
+    144 / 100 tokens — same parity bar."""
+    kw = dict(dca.small_unet_kwargs(), sample_size=size)
+    m, o = make_pair(kw, seed=6)
+    torch.manual_seed(7)
+    x, lam, emb = torch.randn(3, 3, size, size), torch.tensor([3.0, 0.0, -4.0]), torch.randn(3, 1, 64)
+    ref = o(x, lam, encoder_hidden_states=emb)
+    got = m.to(DEV)(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu()
+    assert got.shape == ref.shape
+    assert relerr(got, ref) < 2e-5, relerr(got, ref)
+
+
 def test_small_unet_forward_f32_with_large_activation_offsets():
     """A checkpoint-like failure mode random weights never show: conv biases far larger than the activations' spread, so that every
     GroupNorm sees groups with |mean| >> std (tens of standard deviations here; the offsets differ per group).  The fp32 path must
