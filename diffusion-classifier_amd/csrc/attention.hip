@@ -5,7 +5,8 @@
 // the single class token needs no kernel: softmax over one key is 1, see DESIGN.md.)
 //
 // UNet shapes are tiny (L<=256 tokens, d<=128; <0.5 % of the forward's FLOPs), so this kernel
-// keeps everything on-chip and exact in fp32: K and V of one (sample, head) live in LDS as f32,
+// keeps everything on-chip and exact in fp32: K and V of one (sample, head) live in LDS as f32
+// (longer sequences — the fp32 parity path of the DiTs — stream them through LDS in blocks),
 // each query is owned by d/16 adjacent lanes holding a 16-wide slice of q and of the output,
 // scores are reduced across those lanes with xor-shuffles, softmax is online (running max / sum).
 #include <stdlib.h>
@@ -14,6 +15,7 @@
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* out;
   int n, L, heads, d, ld_qkv, ld_out; float scale;
+  int KB;     // keys per LDS block: L when the whole sequence fits (the UNets), else 8192 / d (the fp32 parity path of the DiTs)
 };
 
 template <typename T>
@@ -26,15 +28,9 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs a) {
   int b = blockIdx.x;
   const int qt = b % qtiles; b /= qtiles;
   const int h = b % a.heads; const int n = b / a.heads;
-  float* Ks = kv; float* Vs = kv + a.L * a.d;
+  float* Ks = kv; float* Vs = kv + a.KB * a.d;
   const T* kb = reinterpret_cast<const T*>(a.k) + (size_t)n * a.L * a.ld_qkv + h * a.d;
   const T* vb = reinterpret_cast<const T*>(a.v) + (size_t)n * a.L * a.ld_qkv + h * a.d;
-  for (int i = t; i < a.L * a.d; i += 256) {
-    const int r = i / a.d, c = i - r * a.d;
-    Ks[i] = Elem<T>::to_f(kb[(size_t)r * a.ld_qkv + c]);
-    Vs[i] = Elem<T>::to_f(vb[(size_t)r * a.ld_qkv + c]);
-  }
-  __syncthreads();
   const int sl = t % DS;                         // my 16-wide slice of d
   const int qi = qt * QT + t / DS;               // my query
   const bool live = qi < a.L;
@@ -43,20 +39,32 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs a) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) { qv[e] = Elem<T>::to_f(qp[e]) * a.scale; o[e] = 0.f; }
   float m = -INFINITY, l = 0.f;
-  for (int j = 0; j < a.L; ++j) {
-    const float* kj = Ks + j * a.d + sl * 16;
-    float s = 0.f;
+  // keys stream through LDS in blocks of KB (one block = the whole sequence for the UNets' token counts): the online softmax
+  // does not care where a block ends, so long sequences (DiT-B/4: 1024 / 4096 tokens) take the same fp32-exact path
+  for (int j0 = 0; j0 < a.L; j0 += a.KB) {
+    const int nk = min(a.KB, a.L - j0);
+    if (j0) __syncthreads();                     // everyone is done with the previous block
+    for (int i = t; i < nk * a.d; i += 256) {
+      const int r = i / a.d, c = i - r * a.d;
+      Ks[i] = Elem<T>::to_f(kb[(size_t)(j0 + r) * a.ld_qkv + c]);
+      Vs[i] = Elem<T>::to_f(vb[(size_t)(j0 + r) * a.ld_qkv + c]);
+    }
+    __syncthreads();
+    for (int j = 0; j < nk; ++j) {
+      const float* kj = Ks + j * a.d + sl * 16;
+      float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s += qv[e] * kj[e];
-    for (int off = 1; off < DS; off <<= 1) s += __shfl_xor(s, off, 64);
-    const float mn = fmaxf(m, s);
-    const float corr = expf(m - mn);
-    const float p = expf(s - mn);
-    l = l * corr + p;
-    const float* vj = Vs + j * a.d + sl * 16;
+      for (int e = 0; e < 16; ++e) s += qv[e] * kj[e];
+      for (int off = 1; off < DS; off <<= 1) s += __shfl_xor(s, off, 64);
+      const float mn = fmaxf(m, s);
+      const float corr = expf(m - mn);
+      const float p = expf(s - mn);
+      l = l * corr + p;
+      const float* vj = Vs + j * a.d + sl * 16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = o[e] * corr + p * vj[e];
-    m = mn;
+      for (int e = 0; e < 16; ++e) o[e] = o[e] * corr + p * vj[e];
+      m = mn;
+    }
   }
   if (live) {
     const float inv = 1.0f / l;
@@ -86,12 +94,14 @@ extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   if (!no_mfma && dc_attn_wave_applicable(p)) return dc_attn_wave_launch(p, reinterpret_cast<hipStream_t>(stream));
   if (!no_mfma && p->L <= mfma_maxl && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
   static const bool force_flash = getenv("DCAMD_ATTN_FLASH") != nullptr;
-  const size_t lds = (size_t)2 * p->L * p->d * sizeof(float);
-  if (!no_mfma && (lds > 160 * 1024 || force_flash || p->L > mfma_maxl) && dc_attn_flash_applicable(p->dtype, p->L, p->d))
+  const size_t lds_all = (size_t)2 * p->L * p->d * sizeof(float);
+  if (!no_mfma && (lds_all > 160 * 1024 || force_flash || p->L > mfma_maxl) && dc_attn_flash_applicable(p->dtype, p->L, p->d))
     return dc_attn_flash_launch(p, reinterpret_cast<hipStream_t>(stream));
-  DC_REQUIRE(lds <= 160 * 1024, DC_ERR_UNSUPPORTED,
-             "dc_attention: L=%d d=%d needs %zu B of LDS (>160 KiB); long-sequence path not built yet", p->L, p->d, lds);
-  AttnArgs a{p->q, p->k, p->v, p->out, p->n, p->L, p->heads, p->d, p->ld_qkv, p->ld_out, p->scale};
+  // fp32 (the parity path) and shapes the matrix-core kernels do not take: exact fp32 kernel; K / V stay whole in LDS when they
+  // fit 160 KiB (one block: the order of operations of the UNet parity path is unchanged), else stream in 64 KiB blocks
+  const int KB = lds_all <= 160 * 1024 ? p->L : 8192 / p->d;
+  const size_t lds = (size_t)2 * KB * p->d * sizeof(float);
+  AttnArgs a{p->q, p->k, p->v, p->out, p->n, p->L, p->heads, p->d, p->ld_qkv, p->ld_out, p->scale, KB};
   const int DS = p->d / 16, QT = 256 / DS, qtiles = (p->L + QT - 1) / QT;
   const long long nb = (long long)p->n * p->heads * qtiles;
   DC_REQUIRE(nb < (1LL << 31), DC_ERR_SHAPE, "dc_attention: grid too large");

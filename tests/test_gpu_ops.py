@@ -484,8 +484,6 @@ def test_attention_with_large_logits(dt, Ld):
     exp() of an unshifted logit overflows fp32 at 88 and f16 at 11: every kernel (one wave per pair, whole-sequence, flash, the
     fp32 fallback) must subtract the row maximum — the result has to be finite and equal to torch's, rows that are one-hot included."""
     Lq, d = Ld
-    if dt == L.DC_F32 and Lq > 256:
-        pytest.skip("fp32 attention is the parity path of the UNets: short sequences only")
     torch.manual_seed(26)
     n, heads = 2, 2
     Cc = heads * d
@@ -510,10 +508,26 @@ def test_attention_with_large_logits(dt, Ld):
     assert (got - ref).abs().max().item() < {L.DC_F32: 2e-4, L.DC_BF16: 4e-2, L.DC_F16: 6e-3}[dt]
 
 
-def test_attention_f32_long_sequence_is_refused_loudly():
-    x = torch.zeros(1, device=DEV)
-    p = L.AttentionParams(q=ptr(x), k=ptr(x), v=ptr(x), out=ptr(x), dtype=0, n=1, L=4096, heads=1, d=64, ld_qkv=192, ld_out=64, scale=1)
-    assert L.lib().dc_attention(p, L.stream_ptr()) == -6 and b"LDS" in L.lib().dc_last_error()   # never a silent wrong answer
+@pytest.mark.parametrize("Ld", [(1024, 64), (4096, 64), (700, 128), (2000, 32)])
+def test_attention_f32_long_sequences(Ld):
+    """The fp32 parity path at DiT token counts (1024 = DWT 128^2 / patch 4, 4096 = raw 256^2) and ragged lengths: K / V no longer fit
+    LDS whole, the exact fp32 kernel streams them in blocks through its online softmax."""
+    Lq, d = Ld
+    torch.manual_seed(17)
+    n, heads = 1, 2
+    Cc = heads * d
+    qkv = torch.randn(n, Lq, 3 * Cc) * 1.5
+    sh = lambda z: z.view(n, Lq, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sh(qkv[..., :Cc]).double(), sh(qkv[..., Cc:2 * Cc]).double(), sh(qkv[..., 2 * Cc:]).double())
+    ref = ref.transpose(1, 2).reshape(n, Lq, Cc).float()
+    qd = qkv.to(DEV)
+    out = torch.full((n, Lq, Cc), float("nan"), device=DEV)
+    p = L.AttentionParams(q=qd.data_ptr(), k=qd.data_ptr() + Cc * 4, v=qd.data_ptr() + 2 * Cc * 4, out=ptr(out), dtype=L.DC_F32,
+                          n=n, L=Lq, heads=heads, d=d, ld_qkv=3 * Cc, ld_out=Cc, scale=d ** -0.5)
+    L.check(L.lib().dc_attention(p, L.stream_ptr()), "attn")
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 5e-5      # outputs are O(1); fp32 running sums over up to 4096 keys
 
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16])
