@@ -93,10 +93,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # DCAMD_BENCH_REHEARSE=1: rehearsal of the N-rank harness on a box with fewer GPUs than ranks — ranks share the devices
+    # round-robin and talk over gloo (RCCL refuses two ranks on one device).  Never a measurement: the line says so in `data`.
+    rehearse = os.environ.get("DCAMD_BENCH_REHEARSE") is not None and world > 1
+    if rehearse:
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import diffusion_classifier_amd as dca
     arch_fn, enc, classes, T, ipg, flop_fwd = WORKLOADS[args.workload]
@@ -151,7 +159,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     sink, dc._timed_sink = dc._timed_sink, None
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
@@ -213,7 +221,7 @@ def main():
                value=round(value, 3), unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                scaling="strong" if args.global_batch else "weak", vs_baseline=None,
-               dtype=args.dtype, data="synthetic",
+               dtype=args.dtype, data="synthetic" + (" (REHEARSAL: ranks share devices, gloo — not a measurement)" if rehearse else ""),
                config=dict(workload=args.workload, images_per_step=B, classes=classes, trials=T,
                            forwards_per_image=classes * T, share_trunk=not args.no_share_trunk,
                            stages=args.stages, input="haar_dwt2(x0)/2 (HIP kernel)" if dwt else "uniform [-1,1]",

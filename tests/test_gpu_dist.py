@@ -53,3 +53,22 @@ def test_cfg2_architecture_bf16_world_size_3_is_bit_identical_to_world_size_1(tm
     for r in three:
         for k in ("lab", "err", "lab_p", "err_p"):
             np.testing.assert_array_equal(r[k], one[k])
+
+
+def test_bench_harness_with_three_ranks_rehearsed_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 3` exactly as typed by hand — the parent starts torch.distributed.run as a child, the ranks rendezvous on
+    127.0.0.1, shard the grid, take the max time over ranks, rank 0 prints ONE JSON line — rehearsed with DCAMD_BENCH_REHEARSE=1 (ranks
+    share cuda:0 and talk over gloo, since RCCL refuses two ranks on one device).  The line must carry the contract's fields and say
+    that it is a rehearsal."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, DCAMD_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--workload", "small-unet-2x8"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["config"]["parallelism"] == "grid-shard x3" and d["config"]["images_per_step"] == 24
+    assert "REHEARSAL" in d["data"] and "roofline" in d and "cpu_baseline" not in d
