@@ -358,3 +358,50 @@ def test_sample_on_hip_backbone_matches_cpu_backbone():
     finally:
         torch.randn_like = real
     assert (got - ref).abs().max().item() < 2e-3       # 4 chained fp32 forwards with a clip in between
+
+
+def _small_dit_classifiers(cfg, seed=13):
+    kw = dict(num_attention_heads=2, attention_head_dim=32, in_channels=4, num_layers=2, sample_size=16, patch_size=4, num_embeds_ada_norm=10)
+    torch.manual_seed(seed)
+    m = dca.DiT(**kw)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    o = oracle.OracleDiT(**kw)
+    o.load_state_dict(m.state_dict())
+    return dca.DiffusionClassifier(m, dca.Config(**cfg)).to(DEV), oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+
+
+@pytest.mark.parametrize("variant", ["dit_three_stage_v", "dit_fast", "unet_one_cell", "unet_three_stage_odd_batch"])
+def test_classify_f32_schedule_corners_match_oracle(variant):
+    """Corners of the scoring loop the main variants do not reach: the label-table (DiT) encoder under three pruning stages with
+    v-prediction and under fast mode (3 of 6 classes), a 1 image x 2 classes x 1 trial grid, three stages over 9 classes with an odd
+    batch — per-cell errors within 1e-4, the same cells evaluated, identical labels."""
+    dcfg = dict(BASE, encoder_type="DiT", image_size=16, noise_d=16)
+    fast, lab, fsel = False, None, None
+    if variant == "dit_three_stage_v":
+        dc, oc = _small_dit_classifiers(dict(dcfg, classes=8, pred_param="v", n_stages=3, evaluation_per_stage=[1, 3, 6], n_keep_per_stage=[4, 2, 1]))
+        x, T = torch.rand(3, 4, 16, 16) * 2 - 1, 6
+    elif variant == "dit_fast":
+        dc, oc = _small_dit_classifiers(dict(dcfg, classes=6, n_fast_classes=3, evaluation_per_stage=[4]))
+        x, T = torch.rand(3, 4, 16, 16) * 2 - 1, 4
+        fast, lab, fsel = True, torch.tensor([1, 5, 0]), torch.tensor([[0, 3], [1, 2], [4, 0]])
+    elif variant == "unet_one_cell":
+        dc, oc = _classifiers(dca.small_unet_kwargs(), dict(BASE, classes=2, evaluation_per_stage=[1]), seed=21)
+        x, T = torch.rand(1, 3, 32, 32) * 2 - 1, 1
+    else:
+        dc, oc = _classifiers(dca.small_unet_kwargs(), dict(BASE, classes=9, n_stages=3, evaluation_per_stage=[1, 2, 4], n_keep_per_stage=[5, 2, 1]), seed=22)
+        x, T = torch.rand(5, 3, 32, 32) * 2 - 1, 4
+    torch.manual_seed(99)
+    t, eps = torch.rand(T, x.shape[0]), torch.randn(T, *x.shape)
+    if fast:
+        ref_l, ref_e = oc.classify(x, lab, fast=True, t=t, eps=eps, fast_select=fsel, return_errors=True)
+        got_l, got_e = dc.classify(x.to(DEV), lab.to(DEV), fast=True, t=t, eps=eps.to(DEV), fast_select=fsel, return_errors=True)
+    else:
+        ref_l, ref_e = oc.classify(x, t=t, eps=eps, return_errors=True)
+        got_l, got_e = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    fin = torch.isfinite(ref_e)
+    assert torch.equal(torch.isfinite(got_e), fin)
+    assert ((got_e[fin] - ref_e[fin]).abs() / ref_e[fin]).max().item() < 1e-4
+    assert got_l.cpu().tolist() == ref_l.tolist()
