@@ -240,6 +240,10 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
       };
       // one (sample, part) record set from pixel fragments [J0, J1) of the wave
       auto emit = [&](auto j0c, auto j1c, int h) {
+        // the half-tile instances (8x8 images: two per wave tile) and the whole-tile one must do the SAME arithmetic, or an image's
+        // statistics would depend on which half of a patch — i.e. on how many units share a launch — it sits in: no implicit
+        // contraction in here, fused multiply-adds only where written
+#pragma clang fp contract(off)
         constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
         float piv[NK][2];
         f32x2 sm[NK][2], sq[NK][2];                               // [run][quad]: (even, odd) register pairs, folded at the end
@@ -260,7 +264,7 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
               for (int e = 0; e < 4; e += 2) {
                 const f32x2 d = f32x2{acc[2 * k + qd][j][e], acc[2 * k + qd][j][e + 1]} - f32x2{piv[k][qd], piv[k][qd]};
                 sm[k][qd] += d;
-                sq[k][qd] += d * d;
+                sq[k][qd] = __builtin_elementwise_fma(d, d, sq[k][qd]);
               }
         const float inv_n = 1.0f / (float)((J1 - J0) * 16 * 4);    // values per quad record
         float r[NK][4];
@@ -269,8 +273,8 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
           for (int qd = 0; qd < 2; ++qd) {
             const float S = row_sum(sm[k][qd][0] + sm[k][qd][1]), Q = row_sum(sq[k][qd][0] + sq[k][qd][1]);
-            r[k][2 * qd] = piv[k][qd] + S * inv_n;
-            r[k][2 * qd + 1] = fmaxf(Q - S * S * inv_n, 0.f);
+            r[k][2 * qd] = __builtin_fmaf(S, inv_n, piv[k][qd]);
+            r[k][2 * qd + 1] = fmaxf(__builtin_fmaf(-S * S, inv_n, Q), 0.f);
           }
         int n = 0, part = 0;
         if ((threadIdx.x & 15) == 0 && qsfn(h, n, part)) {
