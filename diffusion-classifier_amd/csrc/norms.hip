@@ -32,7 +32,7 @@ struct GnAcc {
     m2 += m22 + d * d * (n * w);
     n = nt;
   }
-  __device__ __forceinline__ float var() const { return n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f; }
+  __device__ __forceinline__ float var() const { return n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f; }     // a division: never contracted
 };
 // merge of many (count, mean, M2) sets in ONE pass without a division per set: shifted by the first set's mean,
 // N = sum n, S1 = sum n d, S3 = sum n d^2 (d = mean - pivot), S2 = sum M2  ->  mean = pivot + S1/N, M2 = S2 + S3 - S1^2/N
@@ -79,19 +79,21 @@ __device__ __forceinline__ GnAcc gn_fold_ws(const GnArgs& a, int n, int g, int c
 // the group's quads inner, the means shifted by the first record's (what is left inside the shifted sums is the spread of the
 // record means, which is part of the group's variance): as many loads as the sum / sum-of-squares form had, no division per record
 __device__ __forceinline__ GnAcc gn_fold_rec(const float2* rec, int qparts, int CQ, int g, int qpg, float nq) {
+  // inlined into four kernels (image / span / affine sweeps) that must agree bit for bit: no implicit contraction
+#pragma clang fp contract(off)
   const float piv = rec[g * qpg].x;
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   for (int part = 0; part < qparts; ++part)
     for (int q = g * qpg; q < (g + 1) * qpg; ++q) {
       const float2 v = rec[(size_t)part * CQ + q];
       const float d = v.x - piv;
-      s1 += d; s3 += d * d; s2 += v.y;
+      s1 += d; s3 = __builtin_fmaf(d, d, s3); s2 += v.y;
     }
   const float R = (float)(qparts * qpg), iR = 1.0f / R;
   GnAcc A;
   A.n = R * nq;
-  A.mean = piv + s1 * iR;
-  A.m2 = s2 + nq * fmaxf(s3 - s1 * s1 * iR, 0.f);
+  A.mean = __builtin_fmaf(s1, iR, piv);
+  A.m2 = __builtin_fmaf(nq, fmaxf(__builtin_fmaf(-s1 * s1, iR, s3), 0.f), s2);
   return A;
 }
 
