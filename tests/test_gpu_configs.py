@@ -287,3 +287,29 @@ def test_cfg2_full_grid_properties_at_bench_size():
     assert torch.equal(ebc[:, :, 10:][kept], e1c[:, :, 10:][kept])
     masked = torch.where(kept, e1c.mean(2), torch.full((4, 10), float("inf")))
     assert lb.cpu().tolist() == masked.argmin(1).tolist()
+
+
+@pytest.mark.parametrize("which", ["cfg3_bf16", "cfg5_f16"])
+def test_other_architectures_are_launch_size_independent(which):
+    """The invariance `north_star`'s sharding rests on — a (image, class, trial) cell's error does not depend on which other units share
+    its launch — on the CheXpert-DWT UNet (multi-patch images, split GroupNorm with folded quad records) and on DiT-B/4 (flash
+    attention, adaLN): three micro-batch sizes, bit-identical per-cell errors."""
+    kwfn, enc, classes, dt = (("chexpert_dwt_unet_kwargs", "nn", 2, "bf16") if which == "cfg3_bf16" else ("chexpert_dit_b4_kwargs", "DiT", 2, "f16"))
+    kw = getattr(dca, kwfn)()
+    torch.manual_seed(0)
+    m = dca.UNetCondition2D(**kw) if enc == "nn" else dca.DiT(**kw)
+    size, cin = kw["sample_size"], kw["in_channels"]
+    T, B = 7, 2
+    cfg = dict(pred_param="eps", schedule="cosine", noise_d=size, image_size=size, cfg_w=0.0, ema_beta=0.999, ema_warmup=0, ema_update_freq=1,
+               encoder_type=enc, classes=classes, n_stages=1, evaluation_per_stage=[T], n_keep_per_stage=[1], n_fast_classes=2, compute_dtype=dt)
+    dc = dca.DiffusionClassifier(m, dca.Config(**cfg)).to(DEV)
+    torch.manual_seed(1)
+    x = (torch.rand(B, cin, size, size) * 2 - 1).to(DEV)
+    t = torch.rand(T, B)
+    outs = []
+    for upl in (None, classes * 3, classes * 5):
+        dc.config.units_per_launch = upl
+        _, e = dc.classify(x, t=t, rng="philox", seed=3, return_errors=True)
+        outs.append(e.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
