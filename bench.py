@@ -190,7 +190,9 @@ def main():
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_unit="HBM bytes/launch (PMC)",
                     alg_bytes_per_launch=round(d["bytes"] / d["launches"]), launches=d["launches"],
                     avg_launch_ms=round(d["ms"] / d["launches"], 5),
-                    alg_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 4))
+                    alg_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 4),
+                    note="peak = dense spec at 2.4 GHz; measured with rocm-smi, every kernel family of this step runs at the socket power "
+                         "cap (~1.37 kW) with the shader clock at 2.08-2.18 GHz (DESIGN.md 6c, profiles/r02_power_probe.log)")
     total_ms = sum(v["ms"] for v in fam.values())
     kernels = {k: dict(ms=round(v["ms"], 3), share=round(v["ms"] / total_ms, 4), launches=v["launches"],
                        tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) if v["flops"] else None,
