@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCAMD_LIB") or os.path.join(_HERE, "libdcamd.so")   # DCAMD_LIB: diagnostic builds only
 
+ABI_VERSION = 2      # include/dcamd.h DC_ABI_VERSION
 DC_F32, DC_BF16, DC_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GELU_TANH = 0, 1, 2, 3
 OP_QSAMPLE, OP_SINUSOID, OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_EPS_MSE = 1, 2, 3, 4, 5, 6, 7
@@ -69,6 +70,12 @@ class EpsMseParams(C.Structure):
                 ("out", vp), ("n_units", i32), ("C", i32), ("H", i32), ("W", i32), ("ld", i32), ("v_param", i32), ("patch", i32)]
 
 
+class DdpmStepParams(C.Structure):
+    _fields_ = [("z", vp), ("pred", vp), ("noise", vp), ("out", vp),
+                ("n", i32), ("C", i32), ("H", i32), ("W", i32), ("ld", i32), ("patch", i32), ("v_param", i32),
+                ("w", f32), ("alpha_t", f32), ("sigma_t", f32), ("alpha_s", f32), ("c", f32), ("sd", f32)]
+
+
 class Op(C.Structure):
     _fields_ = [("kind", i32), ("pad_", i32), ("params", vp)]
 
@@ -76,7 +83,7 @@ class Op(C.Structure):
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
            "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_igemm_side_ok", "dc_igemm_ln_ok", "dc_igemm_qstats_parts", "dc_igemm_up4_ok", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
-           "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_haar_dwt2", "dc_haar_idwt2", "dc_stage_topk", "dc_reduce_argmin", "dc_stage_maps", "dc_run_plan", "dc_run_plan_timed",
+           "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_ddpm_step", "dc_haar_dwt2", "dc_haar_idwt2", "dc_stage_topk", "dc_reduce_argmin", "dc_stage_maps", "dc_run_plan", "dc_run_plan_timed",
            "dc_packed_bytes", "dc_pack_weights_matrix", "dc_pack_weights_conv3x3", "dc_pack_weights_up4", "dc_pack_weights_geglu",
            "dc_fold_layernorm_bias", "dc_workspace_bytes_groupnorm", "dc_workspace_bytes_igemm", "dc_workspace_bytes_attention",
            "dc_workspace_bytes_layernorm"]
@@ -108,6 +115,7 @@ def lib():
                        ("dc_layernorm", [C.POINTER(LayernormParams), vp]),
                        ("dc_attention", [C.POINTER(AttentionParams), vp]),
                        ("dc_eps_mse", [C.POINTER(EpsMseParams), vp]),
+                       ("dc_ddpm_step", [C.POINTER(DdpmStepParams), vp]),
                        ("dc_run_plan", [C.POINTER(Op), i32, vp]),
                        ("dc_run_plan_timed", [C.POINTER(Op), i32, vp, vp]),
                        ("dc_philox_normal", [vp, i64, i64, vp, u64, vp]),
@@ -148,8 +156,8 @@ def lib():
     L.dc_groupnorm_ws_floats.restype = i64
     L.dc_groupnorm_splits.argtypes = [i32, i32, i32]
     L.dc_groupnorm_splits.restype = i32
-    if L.dc_abi_version() != 1:
-        raise DcamdError(f"libdcamd ABI {L.dc_abi_version()} != 1")
+    if L.dc_abi_version() != ABI_VERSION:
+        raise DcamdError(f"libdcamd ABI {L.dc_abi_version()} != {ABI_VERSION} (stale libdcamd.so? rebuild with `make -C diffusion-classifier_amd/csrc`)")
     _lib = L
     return L
 

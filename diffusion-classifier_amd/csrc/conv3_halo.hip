@@ -590,6 +590,9 @@ __global__ __launch_bounds__(256, 2) void conv3_thin_kernel(const IgemmArgs a, c
         gnp[c] = a.gn_scale[(size_t)ng * Ctot + c];
         gnp[Ctot + c] = a.gn_shift[(size_t)ng * Ctot + c];
       }
+    // the table is read by OTHER waves after the chunk loop's first raw s_barrier, which waits for no counter (and hwait_vmcnt
+    // covers vmcnt only): drain this wave's LDS writes here
+    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
   }
   issue(0);
   for (int cc = 0; cc < nchunks; ++cc) {

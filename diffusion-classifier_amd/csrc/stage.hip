@@ -7,13 +7,22 @@
 // One wave per image.  Lane l owns classes l, l+64, ...; the mean of a class is the fp32 sum over j = 0 .. t_end-1 in
 // ascending order divided by t_end (inf for a class with an unevaluated cell, which is then never kept) — the order
 // depends on nothing but (t_end), so every rank and every world size selects the same classes.  Selection: k rounds of a
-// wave-wide arg-min on (mean, class id), ties to the lower class id; output ascending by mean like torch.topk(largest=False).
+// wave-wide arg-min on (order key of the mean, class id), ties to the lower class id; output ascending by mean like
+// torch.topk(largest=False), which the host path this replaces used (reference :720): a NaN mean (an overflowed f16 forward:
+// inf - inf) sorts AFTER +inf there, so it does here — the key maps every NaN to the largest value.  Taken classes are tracked
+// in a per-lane bit mask, so each of the k <= C rounds yields a valid class id whatever the values are.
+__device__ __forceinline__ uint32_t stage_order_key(float v) {
+  if (v != v) return 0xFFFFFFFFu;                          // NaN: last
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // monotone in v (the caller folds -0 into +0 first)
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(64) void stage_topk_kernel(const float* __restrict__ errors, int C, int T, int t_end, int k,
                                                         OutT* __restrict__ keep, float* __restrict__ means) {
   constexpr int MAXPL = 16;                     // classes per lane: C <= 1024
   const int b = blockIdx.x, lane = threadIdx.x;
-  float m[MAXPL];
+  uint32_t m[MAXPL];
 #pragma unroll
   for (int i = 0; i < MAXPL; ++i) {
     const int c = lane + 64 * i;
@@ -25,26 +34,27 @@ __global__ __launch_bounds__(64) void stage_topk_kernel(const float* __restrict_
       s = s / (float)t_end;
       if (means) means[(size_t)b * C + c] = s;
     }
-    m[i] = s;
+    s = s + 0.f;                                // -0 -> +0 (they compare equal in torch: one key)
+    m[i] = stage_order_key(s);
   }
+  uint32_t taken = 0;                           // bit i: class lane + 64 i was selected in an earlier round
   for (int r = 0; r < k; ++r) {
-    float bv = __builtin_inff();
+    uint32_t bv = 0xFFFFFFFFu;
     int bc = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < MAXPL; ++i) {
       const int c = lane + 64 * i;
-      if (c < C && (m[i] < bv || (m[i] == bv && c < bc))) { bv = m[i]; bc = c; }
+      if (c < C && !((taken >> i) & 1u) && (m[i] < bv || (m[i] == bv && c < bc))) { bv = m[i]; bc = c; }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-      const float ov = __shfl_xor(bv, off, 64);
+      const uint32_t ov = (uint32_t)__shfl_xor((int)bv, off, 64);
       const int oc = __shfl_xor(bc, off, 64);
       if (ov < bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
     }
+    // k <= C and every untaken class of a lane is a candidate (a NaN key equals the initial bv and wins on c < bc): bc is a class id
     if (lane == 0) keep[(size_t)b * k + r] = (OutT)bc;
-#pragma unroll
-    for (int i = 0; i < MAXPL; ++i)
-      if (lane + 64 * i == bc) m[i] = __builtin_nanf("");       // taken: NaN never compares smaller or equal
+    if ((bc & 63) == lane) taken |= 1u << (bc >> 6);
   }
 }
 
@@ -85,7 +95,8 @@ __global__ __launch_bounds__(256) void stage_maps_kernel(const int32_t* __restri
     if (pad) r = m * n_bj;
     const long long g = rank + (long long)r * world;
     const int j = t0 + (int)(g / BS), b = (int)(g % BS);
-    const int cls = keep[(size_t)b * k + c];
+    int cls = keep[(size_t)b * k + c];
+    cls = cls < 0 ? 0 : (cls >= C ? C - 1 : cls);       // keep[] comes from dc_stage_topk (always a class id); a foreign list must not index out of errors[]
     int32_t* row = maps + (size_t)m * 2 * U;
     row[u] = cls;
     row[U + u] = pad ? dump : (b * C + cls) * T + j;

@@ -15,13 +15,17 @@ grid is flattened into micro-batches of work units; each micro-batch is ONE nati
 (`dc_run_plan`) that enqueues q_sample -> backbone -> eps-MSE on the HIP stream, with z_t / eps
 materialised once per (image, trial), class-independent layers computed once per (image,
 trial), and errors scattered straight into `errors[b, class, j]`.  The stage end (mean over
-trials, top-k smallest, :718-721) runs on the gathered `errors` tensor with the same torch ops
-as the reference, identically on every rank.
+trials, top-k smallest, :718-721) runs ON THE DEVICE for the HIP backbones (`dc_stage_topk`,
+`dc_reduce_argmin`: fixed summation order, ties to the lower class id, NaN last — identical on
+every rank), and so do the next stage's work-unit maps (`dc_stage_maps`): nothing is copied to
+the host between stages.  A foreign `nn.Module` backbone takes the reference's own torch ops
+(`_ForeignRunner.stage_end`).
 
 Extra keyword-only arguments (defaults keep the reference behaviour):
   t, eps         inject the per-trial draws ([T,BS] and [T,BS,C,H,W]) — parity tests
   fast_select    inject the `randint` draw of fast mode
-  return_errors  also return errors[BS, classes, T] (CPU)
+  return_errors  also return errors[BS, classes, T] (copied to the CPU; with the multi-GPU gather's host leg under gloo
+                 the only device -> host copies of a classify call)
   rng            "reference": draw rand(BS) / randn_like(x) per trial in the reference's order;
                  "philox":   t from the CPU generator, eps on device from Philox keyed by
                              (seed, image, trial) — no eps traffic, world-size independent
@@ -202,8 +206,10 @@ class DiffusionClassifier(nn.Module):
                 break
         return val_samples, batches, metrics
 
-    # ---- generation (reference :163-293): the backbone calls run on the HIP forward, the ----
-    # ---- per-step sampler algebra is a handful of elementwise torch ops (not on the scoring path)          ----
+    # ---- generation (reference :163-293) ---------------------------------------------------
+    # HIP backbones: ONE batch-2 plan launch per step (class token || null token, the class-independent layers once per
+    # image) and ONE fused sampler-step kernel (`dc_ddpm_step`); a foreign nn.Module takes the reference's two eager calls
+    # and its elementwise torch expressions (`ddpm_sampler_step`, kept for that path and as the fused kernel's statement).
     def clip(self, x):
         return torch.clamp(x, -1, 1)
 
@@ -219,10 +225,27 @@ class DiffusionClassifier(nn.Module):
         mu = alpha_s * (z_t * (1 - c) / alpha_t + c * x_pred)
         return mu, (sigma_s ** 2) * c
 
+    def _fused_sampler_step(self, backbone, z_t, pair, lam_t, lam_s, noise):
+        """`ddpm_sampler_step` + the update `z = mu + noise * sqrt(var)` (noise None: the clipped mean of the last pass) on the
+        prediction pair of `forward_pair`, as one kernel.  The step's scalars are formed by the same fp32 torch ops as above."""
+        lt, ls = lam_t.detach().float().cpu().reshape(()), lam_s.detach().float().cpu().reshape(())
+        c = -torch.special.expm1(lt - ls)
+        alpha_t, alpha_s = torch.sqrt(torch.sigmoid(lt)), torch.sqrt(torch.sigmoid(ls))
+        sigma_t, sigma_s = torch.sqrt(torch.sigmoid(-lt)), torch.sqrt(torch.sigmoid(-ls))
+        sd = torch.sqrt((sigma_s ** 2) * c)
+        N, Cc, H, W = z_t.shape
+        z = z_t.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(z)
+        patch = int(getattr(backbone.config, "patch_size", 0) or 0)
+        p = L.DdpmStepParams(z=z.data_ptr(), pred=pair.data_ptr(), noise=None if noise is None else noise.data_ptr(), out=out.data_ptr(),
+                             n=N, C=Cc, H=H, W=W, ld=pair.shape[-1], patch=patch, v_param=int(self.pred_param == 'v'),
+                             w=float(self.cfg_w), alpha_t=float(alpha_t), sigma_t=float(sigma_t), alpha_s=float(alpha_s), c=float(c), sd=float(sd))
+        L.check(L.lib().dc_ddpm_step(p, L.stream_ptr()), "dc_ddpm_step")
+        return out
+
     @torch.no_grad()
     def sample(self, x, text=None, from_t=1):
-        """Ancestral DDPM sampling with classifier-free guidance: two backbone evaluations per step
-        (class token / null token), same RNG consumption order as the reference."""
+        """Ancestral DDPM sampling with classifier-free guidance (reference :210-293), same RNG consumption order as the reference."""
         dev = x.device
         if from_t == 1:
             z_t = torch.randn(x.shape).to(dev)
@@ -233,11 +256,20 @@ class DiffusionClassifier(nn.Module):
         if text is not None and self.encoder_type is not None:
             cond = self.encode_text_prompt(text).to(dev)
             null = self.encode_text_prompt(torch.full_like(text, self.null_token)).to(dev)
+        backbone = self.ema.ema_model
+        fused = hasattr(backbone, "forward_pair") and cond is not None and z_t.is_cuda
         steps = torch.linspace(from_t, 0.0, self.config.sampling_steps + 1)
         n = len(steps) - 1
         for i in range(n + 1):                                                # the last pass repeats step n-1 and keeps the mean
             u_t, u_s = (steps[i], steps[i + 1]) if i < n else (steps[-2], steps[-1])
             lam_t, lam_s = self.schedule(u_t).to(dev).unsqueeze(0), self.schedule(u_s).to(dev).unsqueeze(0)
+            if fused:
+                pair = backbone.forward_pair(z_t, lam_t, cond, null)
+                if i == n:
+                    return self._fused_sampler_step(backbone, z_t, pair, lam_t, lam_s, None).to(z_t.dtype)
+                noise = torch.randn_like(z_t).to(torch.float32).contiguous()
+                z_t = self._fused_sampler_step(backbone, z_t, pair, lam_t, lam_s, noise).to(z_t.dtype)
+                continue
             pred = self.ema(z_t, lam_t, encoder_hidden_states=cond)
             u_pred = self.ema(z_t, lam_t, encoder_hidden_states=null)
             mu, var = self.ddpm_sampler_step(z_t, pred, u_pred, lam_t.clone().detach(), lam_s.clone().detach())
@@ -250,7 +282,10 @@ class DiffusionClassifier(nn.Module):
     def inference(self, optimizer=None, train_dataloader=None, val_dataloader=None, lr_scheduler=None, metrics=None,
                   plot_function=None, classification=False, from_t=1, checkpoint_folder="checkpoints"):
         """Same arguments and return value as the reference.  No accelerate object: the process's current HIP
-        device is used, batches are moved to it, metrics are summed over `torch.distributed` when initialised."""
+        device is used, batches are moved to it, metrics are summed over `torch.distributed` when initialised —
+        unless `config.shard_grid` is True (every rank then scored the same images: the counters are already global).
+        A caller that grid-shards through `classify(..., group=pg)` instead of the config key drives `classify` itself
+        and owns its metric reduction; this driver only knows the config key."""
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         if self.config.experiment_path is not None:
             os.makedirs(os.path.join(self.config.experiment_path, "inference_images/"), exist_ok=True)

@@ -23,13 +23,25 @@ def world(group=None):
     return 0, 1
 
 
+_replicated_ok = {}      # (group, data_ptr, version, shape, dtype) of batches already compared across their group
+
+
 def assert_replicated(x, group=None):
     """Grid sharding splits the (trial, image) pairs of ONE batch over the ranks: every rank must hold the same x.
-    Compares a cheap fingerprint (shape, sum, sum of squares, a strided sample) across the group."""
+    Compares a cheap fingerprint (shape, sum, sum of squares, a strided sample) across the group, bit for bit (the fp64 words are
+    compared as int64, so a replicated batch that contains NaN still passes).  The check costs a pass over x, a small all-gather and
+    a host sync, so a batch is checked ONCE: a later call with the same tensor storage at the same version (`x._version` counts
+    in-place writes) is known to be replicated — bench.py scores one resident batch many times and must not pay this per step.
+    Every rank takes the same branch: the key is the same on all ranks that passed the same call sequence.  (The guard is against
+    a mis-configured launch — dataloader sharding with grid sharding switched on — which already shows on the first batch; a fresh
+    tensor that recycles the checked one's address at version 0 is not compared again.)"""
+    key = (id(group), x.data_ptr(), x._version, tuple(x.shape), x.dtype)
+    if _replicated_ok.get("key") == key:
+        return
     xf = x.detach().reshape(-1).to(torch.float64)
     step = max(1, xf.numel() // 61)
     fp = torch.cat([torch.tensor([float(x.shape[0]), float(xf.numel())], dtype=torch.float64, device=xf.device),
-                    xf.sum().reshape(1), (xf * xf).sum().reshape(1), xf[::step][:61]])
+                    xf.sum().reshape(1), (xf * xf).sum().reshape(1), xf[::step][:61]]).contiguous().view(torch.int64)
     ws = dist.get_world_size(group)
     if fp.is_cuda and dist.get_backend(group) == "gloo":
         fp = fp.cpu()                    # gloo has no device all-gather
@@ -39,6 +51,7 @@ def assert_replicated(x, group=None):
     if not bool((allfp == allfp[0:1]).all().item()):
         raise RuntimeError("classify(shard_grid=True / group=...) needs the identical image batch on every rank of the group; "
                            "the ranks hold different x (dataloader-sharded launch?). Leave grid sharding off in that case.")
+    _replicated_ok["key"] = key
 
 
 def stage_pairs(stage_start, stage_end, BS):

@@ -105,9 +105,44 @@ class DiT(_HipBackbone):
         dt = E.DT[self.compute_dtype]
         return ED.DiTPlan(self, self.packed_weights(dt, device), n_bj, n_cls, n_ctx, score=score, device=device)
 
+    def _feed(self, plan, x, noise_labels):
+        """lambda and the patch-embedding GEMM operand (p x p patches of x) of a plain forward."""
+        lib = L.lib()
+        dev = x.device
+        N, Cin, H, W = x.shape
+        lam = noise_labels if torch.is_tensor(noise_labels) else torch.tensor([noise_labels])
+        lam = lam.to(dev, torch.float32).reshape(-1)
+        plan.lam.copy_(lam.expand(N) if lam.numel() == 1 else lam)
+        xf = x.detach().to(torch.float32).contiguous()
+        ones = torch.ones(N, dtype=torch.float32, device=dev)
+        zeros = torch.zeros(N, dtype=torch.float32, device=dev)
+        q = L.QsampleParams(x=xf.data_ptr(), eps=xf.data_ptr(), alpha=ones.data_ptr(), sigma=zeros.data_ptr(), img_of_bj=None,
+                            out=plan.a0_buf.data_ptr(), out_dtype=plan.dt, n_bj=N, C=Cin, H=H, W=W,
+                            ld=plan.a0_buf.shape[-1], im2col=2, patch=self.config.patch_size)
+        L.check(lib.dc_qsample(q, L.stream_ptr()), "dc_qsample")
+
+    @torch.no_grad()
+    def forward_pair(self, x, noise_labels, cond, null):
+        """Classifier-free-guidance pair as ONE batch-2 plan launch: unit 2b = image b under label `cond[b]`, unit 2b+1 under the
+        null label `null[b]` (reference `sample`, :255-266, calls the backbone twice per step).  Returns the plan's un-patchified
+        projection [2N, H/p, W/p, ld] fp32 (the layout `dc_ddpm_step` reads with patch = p) — a view the next call overwrites."""
+        L.require_gpu()
+        if not x.is_cuda:
+            raise L.DcamdError("DiT.forward_pair needs CUDA/HIP tensors (no CPU fallback)")
+        dev = x.device
+        N = x.shape[0]
+        key = ("pair", N, str(dev), self.compute_dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self.make_plan(N, 2, None, dev)
+        self._feed(plan, x, noise_labels)
+        plan.ctx_of_unit.copy_(torch.stack([cond.reshape(-1), null.reshape(-1)], dim=1).reshape(-1).to(dev, torch.int32))
+        plan.run()
+        return plan.pred_view()
+
     @torch.no_grad()
     def forward(self, x, noise_labels, encoder_hidden_states=None):
-        lib = L.require_gpu()
+        L.require_gpu()
         if not x.is_cuda:
             raise L.DcamdError("DiT.forward needs CUDA/HIP tensors (no CPU fallback)")
         dev = x.device
@@ -118,17 +153,8 @@ class DiT(_HipBackbone):
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = self.make_plan(N, 1, None, dev)
-        lam = noise_labels if torch.is_tensor(noise_labels) else torch.tensor([noise_labels])
-        lam = lam.to(dev, torch.float32).reshape(-1)
-        plan.lam.copy_(lam.expand(N) if lam.numel() == 1 else lam)
+        self._feed(plan, x, noise_labels)
         plan.ctx_of_unit.copy_(encoder_hidden_states.reshape(-1).to(dev, torch.int32))
-        xf = x.detach().to(torch.float32).contiguous()
-        ones = torch.ones(N, dtype=torch.float32, device=dev)
-        zeros = torch.zeros(N, dtype=torch.float32, device=dev)
-        q = L.QsampleParams(x=xf.data_ptr(), eps=xf.data_ptr(), alpha=ones.data_ptr(), sigma=zeros.data_ptr(), img_of_bj=None,
-                            out=plan.a0_buf.data_ptr(), out_dtype=plan.dt, n_bj=N, C=Cin, H=H, W=W,
-                            ld=plan.a0_buf.shape[-1], im2col=2, patch=p)
-        L.check(lib.dc_qsample(q, L.stream_ptr()), "dc_qsample")
         plan.run()
         g, oc = H // p, cfg.out_channels
         out = plan.pred_view().reshape(N, g, g, p, p, oc)          # un-patchify: nhwpqc -> nchpwq

@@ -257,7 +257,7 @@ class UNetCondition2D(_HipBackbone):
                 encoder_hidden_states=None):
         if downblock_additional_residuals is not None or midblock_additional_residuals is not None:
             raise NotImplementedError("ControlNet residuals are not on the scoring path")
-        lib = L.require_gpu()
+        L.require_gpu()
         if not x.is_cuda:
             raise L.DcamdError("UNetCondition2D.forward needs CUDA/HIP tensors (no CPU fallback)")
         dev = x.device
@@ -268,10 +268,43 @@ class UNetCondition2D(_HipBackbone):
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = self.make_plan(N, 1, N, dev)
+        self._feed(plan, x, noise_labels)
+        plan.ctx.copy_(encoder_hidden_states[:, 0].to(dev, torch.float32))
+        plan.run_ctx()
+        plan.run()
+        return plan.pred_view().permute(0, 3, 1, 2).contiguous().to(x.dtype)
+
+
+    @torch.no_grad()
+    def forward_pair(self, x, noise_labels, cond, null):
+        """Classifier-free-guidance pair as ONE batch-2 plan launch (reference `sample`, :255-266, calls the backbone twice per
+        step): unit 2b scores image b under its class token `cond[b]`, unit 2b+1 under the null token `null[b]`; every layer in
+        front of the first cross-attention runs once per image (class-shared trunk).  Returns the plan's prediction buffer
+        [2N, H, W, ld] fp32 NHWC (the layout `dc_ddpm_step` reads) — a view that the next call overwrites."""
+        L.require_gpu()
+        if not x.is_cuda:
+            raise L.DcamdError("UNetCondition2D.forward_pair needs CUDA/HIP tensors (no CPU fallback)")
+        dev = x.device
+        N, Cin, H, W = x.shape
+        key = ("pair", N, str(dev), self.compute_dtype, self.share_trunk)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self.make_plan(N, 2, 2 * N, dev)        # ctx_of_unit = unit index: one context row per unit
+        self._feed(plan, x, noise_labels)
+        ctx = torch.stack([cond[:, 0], null[:, 0]], dim=1).reshape(2 * N, -1)
+        plan.ctx.copy_(ctx.to(dev, torch.float32))
+        plan.run_ctx()
+        plan.run()
+        return plan.pred_view()
+
+    def _feed(self, plan, x, noise_labels):
+        """lambda and the conv_in GEMM operand (3x3 patches of x) of a plain forward."""
+        lib = L.lib()
+        dev = x.device
+        N, Cin, H, W = x.shape
         lam = noise_labels if torch.is_tensor(noise_labels) else torch.tensor([noise_labels])
         lam = lam.to(dev, torch.float32).reshape(-1)
         plan.lam.copy_(lam.expand(N) if lam.numel() == 1 else lam)
-        plan.ctx.copy_(encoder_hidden_states[:, 0].to(dev, torch.float32))
         xf = x.detach().to(torch.float32).contiguous()
         ones = torch.ones(N, dtype=torch.float32, device=dev)
         zeros = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -279,9 +312,6 @@ class UNetCondition2D(_HipBackbone):
                             out=plan.a0_buf.data_ptr(), out_dtype=plan.dt, n_bj=N, C=Cin, H=H, W=W,
                             ld=plan.a0_buf.shape[-1], im2col=1)
         L.check(lib.dc_qsample(p, L.stream_ptr()), "dc_qsample")
-        plan.run_ctx()
-        plan.run()
-        return plan.pred_view().permute(0, 3, 1, 2).contiguous().to(x.dtype)
 
 
 class UNet2D(nn.Module):

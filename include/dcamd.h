@@ -15,6 +15,7 @@
  *   dc_attention        F.scaled_dot_product_attention self-attention (attn1)
  *   dc_eps_mse          diffusion_classifier.py:706-711 (v->eps, torch.norm(...)**2)
  *   dc_haar_dwt2/idwt2  utils/wavelet.py:4-35 / :37-68
+ *   dc_ddpm_step        diffusion_classifier.py:175-208 (ddpm_sampler_step) + :262-266, one fused pass per sampling step
  *   dc_stage_topk / dc_reduce_argmin / dc_stage_maps
  *                       the stage end, diffusion_classifier.py:718-725 (mean over trials, k smallest classes) and the
  *                       per-image surviving-class lists of the next stage (:695-698, ragged after pruning / fast mode
@@ -35,7 +36,8 @@
 extern "C" {
 #endif
 
-#define DC_ABI_VERSION 1
+/* 2: qstats records are (mean, M2) sets (version 1: sum, sum of squares) and qparts must divide HW */
+#define DC_ABI_VERSION 2
 
 typedef void* dc_stream; /* hipStream_t */
 
@@ -231,6 +233,20 @@ typedef struct {
                                k = (py*p+px)*C + c (nets/dit.py un-patchify folded into the read) */
 } dc_eps_mse_params;
 int dc_eps_mse(const dc_eps_mse_params* p, dc_stream s);
+
+/* ---------------------------------------------------------------- sampler step --- */
+/* One ancestral DDPM step with classifier-free guidance (reference :175-208 ddpm_sampler_step + the update :262-266):
+ *   pred = (1 + w) * pred_c - w * pred_u;  x = v_param ? alpha_t z - sigma_t pred : (z - sigma_t pred) / alpha_t;  x = clip(x, -1, 1)
+ *   mu = alpha_s * (z * (1 - c) / alpha_t + c * x);   out = noise ? mu + noise * sd : clip(mu, -1, 1)      (sd = sqrt(sigma_s^2 c))
+ * z / noise / out [n, C, H, W] f32 NCHW; pred [2n, H, W, ld] f32 NHWC, rows 2b (class token) and 2b+1 (null token) of image b —
+ * the output of ONE batch-2 backbone plan (patch > 1: DiT's un-patchified projection as in dc_eps_mse).  Same operation order as
+ * the reference's torch expressions, no contraction: bit-equal to them for the same fp32 scalars. */
+typedef struct {
+  const float* z; const float* pred; const float* noise; float* out;
+  int32_t n, C, H, W, ld, patch, v_param;
+  float w, alpha_t, sigma_t, alpha_s, c, sd;
+} dc_ddpm_step_params;
+int dc_ddpm_step(const dc_ddpm_step_params* p, dc_stream s);
 
 /* ---------------------------------------------------------------- Haar ----------- */
 /* in [n, C, H, W] f32 -> out [n, 4C, H/2, W/2], channel 4i+{0,1,2,3} = cA,cH,cV,cD; out*=scale */

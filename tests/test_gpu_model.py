@@ -360,6 +360,36 @@ def test_sample_on_hip_backbone_matches_cpu_backbone():
     assert (got - ref).abs().max().item() < 2e-3       # 4 chained fp32 forwards with a clip in between
 
 
+@pytest.mark.parametrize("kind", ["unet_v", "dit_eps"])
+def test_sample_batch2_plan_with_fused_step_matches_the_two_call_path(kind):
+    """`sample` on a HIP backbone = one batch-2 plan launch (class token || null token) + one dc_ddpm_step per step; the reference's
+    form (two backbone calls + the elementwise torch expressions, :255-266) on the SAME backbone must give the same images."""
+    cfg = dict(BASE, cfg_w=2.0, sampling_steps=3, classes=4, pred_param="v" if kind == "unet_v" else "eps")
+    if kind == "unet_v":
+        m, _ = make_pair(dca.small_unet_kwargs(), seed=33)
+        dc = dca.DiffusionClassifier(m, dca.Config(**cfg)).to(DEV)
+        x = torch.rand(3, 3, 32, 32) * 2 - 1
+    else:
+        dc, _ = _small_dit_classifiers(dict(cfg, encoder_type="DiT", image_size=16, noise_d=16))
+        x = torch.rand(3, 4, 16, 16) * 2 - 1
+    lab = torch.tensor([1, 3, 0])
+    bb = dc.ema.ema_model
+    assert hasattr(bb, "forward_pair")
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(7)
+        if not fused:
+            real = type(bb).forward_pair
+            del type(bb).forward_pair                   # no pair entry point: `sample` takes the two-call path
+        try:
+            outs.append(dc.sample(x.to(DEV), lab.to(DEV), from_t=0.8).cpu())
+        finally:
+            if not fused:
+                type(bb).forward_pair = real
+    assert outs[0].shape == x.shape and torch.isfinite(outs[0]).all()
+    assert (outs[0] - outs[1]).abs().max().item() < 3e-4, (outs[0] - outs[1]).abs().max().item()    # fp32 plans of different launch shapes
+
+
 def _small_dit_classifiers(cfg, seed=13):
     kw = dict(num_attention_heads=2, attention_head_dim=32, in_channels=4, num_layers=2, sample_size=16, patch_size=4, num_embeds_ada_norm=10)
     torch.manual_seed(seed)

@@ -908,6 +908,61 @@ def test_stage_topk_and_argmin_match_torch(shape):
     L.check(lib.dc_stage_topk(ptr(e2), 2, 5, 3, 3, 3, ptr(k2), None, L.stream_ptr()), "dc_stage_topk")
     assert k2.cpu().tolist() == [[0, 1, 2], [0, 1, 2]]
     assert lib.dc_stage_topk(ptr(e), BS, Cn, T, t_end, Cn + 1, ptr(keep), None, L.stream_ptr()) == -2     # k > classes
+    # NaN means (an overflowed f16 forward: inf - inf) sort LAST, after +inf, as in torch.topk(largest=False); every round still
+    # yields a valid class id — also when fewer than k classes are not NaN, and when every class is NaN
+    e3 = torch.tensor([[[5.0], [float("nan")], [float("inf")], [3.0], [float("nan")], [-0.0], [0.0]],
+                       [[float("nan")]] * 7,
+                       [[float("nan")], [2.0], [float("nan")], [float("nan")], [float("nan")], [float("nan")], [float("nan")]]]).to(DEV)
+    for k3 in (1, 4, 7):
+        k3t = torch.full((3, k3), -1, dtype=torch.int32, device=DEV)
+        L.check(lib.dc_stage_topk(ptr(e3), 3, 7, 1, 1, k3, ptr(k3t), None, L.stream_ptr()), "dc_stage_topk")
+        got = k3t.cpu().long()
+        assert int(got.min()) >= 0 and int(got.max()) < 7
+        assert all(len(set(r)) == k3 for r in got.tolist())                       # k distinct classes per image
+        assert got[0].tolist() == [5, 6, 3, 0, 2, 1, 4][:k3]                       # -0 == +0 (lower id first), ..., inf, then the NaNs by id
+        assert got[1].tolist() == list(range(k3)) and got[2].tolist() == [1, 0, 2, 3, 4, 5, 6][:k3]
+    lab3 = torch.full((3,), -1, dtype=torch.int64, device=DEV)
+    L.check(lib.dc_reduce_argmin(ptr(e3), 3, 7, 1, 1, ptr(lab3), None, L.stream_ptr()), "dc_reduce_argmin")
+    assert lab3.cpu().tolist() == [5, 0, 1]
+    # a class list that is not a class list (a foreign caller) must not index out of errors[]: dc_stage_maps clamps it
+    bad = torch.tensor([[0x7fffffff, -3]], dtype=torch.int32, device=DEV)
+    mp = torch.full((1, 4), -7, dtype=torch.int32, device=DEV)
+    L.check(lib.dc_stage_maps(ptr(bad), 1, 7, 2, 2, 1, 1, 0, 1, 1, 1, 14, ptr(mp), L.stream_ptr()), "dc_stage_maps")
+    assert mp.cpu().tolist() == [[6, 0, (0 * 7 + 6) * 2 + 1, (0 * 7 + 0) * 2 + 1]]
+
+
+def test_ddpm_step_equals_the_torch_expressions():
+    """dc_ddpm_step (reference ddpm_sampler_step :175-208 + the update :262-266 as one pass): bit-equal to the reference's torch
+    expressions for the same fp32 scalars — eps and v parameterisation, image-shaped and DiT-patch prediction layouts, the noise
+    update and the clipped mean of the last pass."""
+    torch.manual_seed(44)
+    N, Cc, H, W = 3, 4, 8, 8
+    z, noise = torch.randn(N, Cc, H, W), torch.randn(N, Cc, H, W)
+    pc, pu = torch.randn(N, Cc, H, W) * 2, torch.randn(N, Cc, H, W) * 2
+    lt, ls, w = torch.tensor(-1.25), torch.tensor(0.75), 1.5
+    c = -torch.special.expm1(lt - ls)
+    a_t, a_s = torch.sqrt(torch.sigmoid(lt)), torch.sqrt(torch.sigmoid(ls))
+    s_t, s_s = torch.sqrt(torch.sigmoid(-lt)), torch.sqrt(torch.sigmoid(-ls))
+    sd = torch.sqrt((s_s ** 2) * c)
+    for v_param in (0, 1):
+        pred = (1 + w) * pc - w * pu
+        xp = a_t * z - s_t * pred if v_param else (z - s_t * pred) / a_t
+        mu = a_s * (z * (1 - c) / a_t + c * torch.clamp(xp, -1, 1))
+        for patch, ld in ((0, 8), (2, 16)):
+            pair = torch.zeros(2 * N, H, W, ld) if not patch else torch.zeros(2 * N, H // patch, W // patch, ld)
+            for b in range(N):
+                for u, src in ((2 * b, pc[b]), (2 * b + 1, pu[b])):
+                    if not patch:
+                        pair[u, :, :, :Cc] = src.permute(1, 2, 0)
+                    else:      # token (ty, tx), k = (py * p + px) * C + c
+                        pair[u] = src.reshape(Cc, H // patch, patch, W // patch, patch).permute(1, 3, 2, 4, 0).reshape(H // patch, W // patch, ld)
+            zd, nd, pd = z.to(DEV), noise.to(DEV), pair.to(DEV)
+            for nz, want in ((nd, mu + noise * sd), (None, torch.clamp(mu, -1, 1))):
+                out = torch.full((N, Cc, H, W), 9.0, device=DEV)
+                p = L.DdpmStepParams(z=ptr(zd), pred=ptr(pd), noise=ptr(nz), out=ptr(out), n=N, C=Cc, H=H, W=W, ld=ld, patch=patch,
+                                     v_param=v_param, w=w, alpha_t=float(a_t), sigma_t=float(s_t), alpha_s=float(a_s), c=float(c), sd=float(sd))
+                L.check(L.lib().dc_ddpm_step(p, L.stream_ptr()), "dc_ddpm_step")
+                assert torch.equal(out.cpu(), want), (v_param, patch, (out.cpu() - want).abs().max())
 
 
 @pytest.mark.parametrize("world,rank", [(1, 0), (3, 1)])

@@ -65,7 +65,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(dca._lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dc_abi_version() == 1
+    assert lib.dc_abi_version() == dca._lib.ABI_VERSION == 2
     lib.dc_arch.restype = ctypes.c_char_p
     assert lib.dc_arch() == b"gfx950"
 
@@ -89,7 +89,8 @@ def test_ctypes_structs_match_header_field_order():
     for struct, cls in [("dc_qsample_params", dca._lib.QsampleParams), ("dc_sinusoid_params", dca._lib.SinusoidParams),
                         ("dc_igemm_params", dca._lib.IgemmParams), ("dc_groupnorm_params", dca._lib.GroupnormParams),
                         ("dc_layernorm_params", dca._lib.LayernormParams), ("dc_attention_params", dca._lib.AttentionParams),
-                        ("dc_eps_mse_params", dca._lib.EpsMseParams), ("dc_op", dca._lib.Op)]:
+                        ("dc_eps_mse_params", dca._lib.EpsMseParams), ("dc_ddpm_step_params", dca._lib.DdpmStepParams),
+                        ("dc_op", dca._lib.Op)]:
         assert fields(struct) == [n for n, _ in cls._fields_], struct
 
 
