@@ -7,7 +7,8 @@ Kept surface (same names, argument meaning, assertions and return types):
   .encode_text_prompt / .diffuse / .logsnr_schedule_cosine(_shifted)  :83-161
 `config` is the reference's attribute bag (missing keys read as None).  Additive keys read
 here: `compute_dtype` ("bf16" default | "f16" | "f32"), `units_per_launch`, `shard_grid` (opt-in: True
-shards the (trial, image) grid of ONE replicated batch over the default process group).
+shards the (trial, image) grid of ONE replicated batch over the default process group),
+`simulate_rank` ((r, N), bench.py only: time rank r's share of an N-rank sharded call on one GPU).
 
 What differs is HOW classify runs.  The reference walks a Python double loop — T trials x C
 classes sequential eager backbone calls at batch BS (:686-714).  Here the (image, trial, class)
@@ -126,7 +127,12 @@ class DiffusionClassifier(nn.Module):
         # must not make ranks mix the errors of different images
         shard = group is not None or cfg.shard_grid is True
         rank, ws = D.world(group) if shard else (0, 1)
-        if ws > 1:
+        # bench.py --simulate-rank r/N (measurement only): score exactly rank r's share of an N-rank grid-sharded call on this one
+        # GPU, without a process group — no replication check, no gather, so the labels of such a call mean nothing
+        sim = cfg.simulate_rank
+        if sim:
+            rank, ws = int(sim[0]), int(sim[1])
+        elif ws > 1:
             D.assert_replicated(x, group)
 
         # candidate classes per image (host, exactly the reference's ops :671-679)
@@ -179,7 +185,8 @@ class DiffusionClassifier(nn.Module):
             pairs = D.local_pairs(ends[i], ends[i + 1], BS, rank, ws)
             runner.run_stage(pairs, classes, stage=(ends[i], rank, ws))
             errors = runner.errors()
-            D.gather_stage_errors(errors, ends[i], ends[i + 1], rank, ws, group=group)
+            if not sim:
+                D.gather_stage_errors(errors, ends[i], ends[i + 1], rank, ws, group=group)
             # stage end (:718-721), identically on every rank: mean over the trials so far, the k smallest classes per image.
             # HIP backbones: on the device (dc_stage_topk / dc_reduce_argmin; the next stage's work-unit maps are built
             # there too), so a multi-stage / fast classify never copies errors to the host between stages.

@@ -8,7 +8,9 @@ tests/golden/classify_*.npz, which were captured from the reference's own `class
 (tools/capture_goldens.py).
 
 The only additions are keyword-only hooks to inject the RNG draws (`t`, `eps`,
-`fast_select`) and to return the `errors[BS, classes, T]` tensor.
+`fast_select`), to return the `errors[BS, classes, T]` tensor and (`return_preds`) the
+backbone's raw outputs `preds[trial, image, class column]` — the quantity the per-cell
+eps-MSE barely sees (it is dominated by ||eps||^2), so the parity tests compare it too.
 """
 import copy
 
@@ -61,7 +63,7 @@ class OracleDiffusionClassifier(nn.Module):
 
     @torch.no_grad()
     def classify(self, x, text=None, fast=False, *, t=None, eps=None, fast_select=None,
-                 return_errors=False):
+                 return_errors=False, return_preds=False):
         cfg = self.config
         assert len(cfg.evaluation_per_stage) == cfg.n_stages          # :660
         assert len(cfg.n_keep_per_stage) == cfg.n_stages              # :661
@@ -70,6 +72,7 @@ class OracleDiffusionClassifier(nn.Module):
         ends = [0] + list(cfg.evaluation_per_stage)                   # :665
         BS = x.shape[0]
         errors = torch.full((BS, cfg.classes, ends[-1]), torch.inf)   # :669
+        preds = {}                                                    # (trial, class column) -> backbone output [BS, C, H, W]
         if fast:                                                      # :671-677
             text = text.view(-1, 1)
             classes = torch.arange(cfg.classes).repeat(BS, 1)
@@ -91,6 +94,8 @@ class OracleDiffusionClassifier(nn.Module):
                     lab = classes[:, c]
                     emb = self.encode_text_prompt(lab)                # :697
                     pred = self.ema_model(x=z, noise_labels=logsnr, encoder_hidden_states=emb)  # :700-704
+                    if return_preds:
+                        preds[(j, c)] = pred
                     eps_pred = sigma * z + alpha * pred if self.pred_param == "v" else pred     # :706-709
                     err = torch.norm((eps_pred - e).view(BS, -1), dim=1, p=2) ** 2              # :711
                     errors[torch.arange(BS), lab, j] = err            # :713-714
@@ -98,4 +103,9 @@ class OracleDiffusionClassifier(nn.Module):
             _, classes = torch.topk(mean, cfg.n_keep_per_stage[i], dim=1, largest=False)  # :720-721
         assert classes.shape[1] == 1                                  # :723
         out = classes[:, 0]                                           # :725
+        if return_preds:       # single-stage grids only: [T, BS, class columns, C, H, W]
+            assert cfg.n_stages == 1
+            ncol = 1 + max(c for _, c in preds)
+            pt = torch.stack([torch.stack([preds[(j, c)] for c in range(ncol)], dim=1) for j in range(ends[-1])])
+            return out, errors, pt
         return (out, errors) if return_errors else out

@@ -27,3 +27,28 @@ def standin_from(g, cfg):
     bb = TinyBackbone(ch=ch, hid=hid, n_classes=cfg["classes"], mode=mode)
     bb.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("bb.")})
     return bb
+
+
+def hip_preds(dc, T, BS):
+    """Backbone outputs of the LAST classify call of `dc` on the HIP path, as [T, BS, class columns, C, H, W] (the layout of the
+    oracle's `return_preds`): read from the score plan's prediction buffer.  Needs a single-stage grid that fitted ONE
+    micro-batch (pairs trial-major, units = pair x class: diffusion_classifier.py _HipRunner.run_stage)."""
+    (sp,) = list(dc._score_plans.values())
+    assert sp["n_bj"] == T * BS, "the grid must fit one micro-batch"
+    plan, k = sp["plan"], sp["k"]
+    pv = plan.pred_view().float().cpu()                         # [U, H, W, ld]
+    bb = dc.ema.ema_model
+    p = int(getattr(bb.config, "patch_size", 0) or 0)
+    if p > 1:                                                   # DiT: [U, g, g, (py*p+px)*C + c] -> [U, C, H, W]
+        U, g, _, _ = pv.shape
+        oc = bb.config.out_channels
+        img = pv[..., :p * p * oc].reshape(U, g, g, p, p, oc).permute(0, 5, 1, 3, 2, 4).reshape(U, oc, g * p, g * p)
+    else:
+        img = pv[..., :bb.config.out_channels].permute(0, 3, 1, 2)
+    return img.reshape(T, BS, k, *img.shape[1:])
+
+
+def pred_rel_l2(got, ref):
+    """Largest per-sample relative L2 error of the predictions (every (trial, image, class) sample on its own)."""
+    g, r = got.double().flatten(3), ref.double().flatten(3)
+    return float(((g - r).norm(dim=3) / r.norm(dim=3).clamp_min(1e-30)).max())

@@ -16,6 +16,7 @@ import torch
 
 import diffusion_classifier_amd as dca
 import oracle
+from helpers import hip_preds, pred_rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -70,12 +71,14 @@ def test_cfg2_classify_f32_bench_plan_matches_oracle(monkeypatch):
     oc = _oracle_for(kw, dc, cfg, lowp=False)
     BS, T = 2, 3
     x, t, eps = _draws(BS, T, 42)
-    ref_l, ref_e = oc.classify(x, t=t, eps=eps, return_errors=True)
+    ref_l, ref_e, ref_p = oc.classify(x, t=t, eps=eps, return_errors=True, return_preds=True)
     dc = dc.to(DEV)
     got_l, got_e = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
     rel = ((got_e - ref_e).abs() / ref_e).max().item()
     assert rel < 1e-4, rel                                                 # north-star bar
     assert got_l.cpu().tolist() == ref_l.tolist()
+    pr = pred_rel_l2(hip_preds(dc, T, BS), ref_p)                          # the benched plan's predictions, every sample on its own
+    assert pr < 5e-5, pr
     plan = next(iter(dc._score_plans.values()))["plan"]
     names = [mt["name"] for mt in plan.pb.meta]
     assert plan.n_cls == 10 and sum(n.endswith(".conv1s") for n in names) == 5      # the class-shared skip halves are in play
@@ -102,12 +105,14 @@ def test_cfg2_classify_bf16_bench_plan_three_anchors():
     oc_f32 = _oracle_for(kw, dc, cfg, lowp=False)
     BS, T = 2, 3
     x, t, eps = _draws(BS, T, 44)
-    lp_l, lp_e = oc_lowp.classify(x, t=t, eps=eps, return_errors=True)
+    lp_l, lp_e, lp_p = oc_lowp.classify(x, t=t, eps=eps, return_errors=True, return_preds=True)
     f32_l, f32_e = oc_f32.classify(x, t=t, eps=eps, return_errors=True)
     with torch.autocast("cpu", dtype=torch.bfloat16):                      # the reference's own bf16 semantics
         ac_l, ac_e = oc_f32.classify(x, t=t, eps=eps, return_errors=True)
     got_l, got_e = dc.to(DEV).classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
     assert torch.isfinite(got_e).all()
+    pr = pred_rel_l2(hip_preds(dc, T, BS), lp_p)
+    assert pr < 1.5e-2, pr                  # predictions of the benched bf16 plan vs the storage-rounded oracle, per sample
     rel = lambda a, b: ((a.float() - b.float()).abs() / b.float()).max().item()
     r_lowp, r_ac, r_f32 = rel(got_e, lp_e), rel(got_e, ac_e), rel(got_e, f32_e)
     print(f"cfg2 bf16 per-cell eps-MSE max rel err: vs storage-rounded oracle {r_lowp:.2e}, vs autocast oracle {r_ac:.2e}, "
@@ -181,6 +186,78 @@ def test_cfg4_ipmsa_unet_forward_bf16():
     assert any(n.startswith("up_blocks.1.resnets.4") for n in names)   # and its mirror has five
 
 
+def test_cfg4_ipmsa_classify_f32_five_class_plan_matches_oracle():
+    """BASELINE config 4 as `classify` runs it: the 6-level tuple-`layers_per_block` UNet (models/ipmsa-5-unet.py:4-30) with FIVE
+    classes per (image, trial) pair — class-shared trunk down to the first cross-attention level and the class-shared skip halves
+    of the up path — in f32 against the oracle: per-cell eps-MSE within 1e-4, identical label, and the plan's five predictions
+    each within 5e-5 (relative L2)."""
+    kw = dca.ipmsa5_unet_kwargs()
+    torch.manual_seed(63)
+    m = dca.UNetCondition2D(**kw)
+    _randomise_vectors(m)
+    cfg = dict(CFG2, classes=5, evaluation_per_stage=[1], image_size=256, noise_d=256, compute_dtype="f32")
+    dc = dca.DiffusionClassifier(m, dca.Config(**cfg))
+    with torch.no_grad():
+        dc.encoder.weight.mul_(3.0)
+    o = oracle.OracleUNetCondition2D(**kw)
+    o.load_state_dict(m.state_dict())
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    oc.encoder.load_state_dict(dc.encoder.state_dict())
+    torch.manual_seed(64)
+    x = torch.rand(1, 10, 256, 256) * 2 - 1
+    t, eps = torch.rand(1, 1), torch.randn(1, 1, 10, 256, 256)
+    ref_l, ref_e, ref_p = oc.classify(x, t=t, eps=eps, return_errors=True, return_preds=True)
+    dc = dc.to(DEV)
+    got_l, got_e = dc.classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    rel = ((got_e - ref_e).abs() / ref_e).max().item()
+    pr = pred_rel_l2(hip_preds(dc, 1, 1), ref_p)
+    print(f"cfg4 f32 classify (1 image x 1 trial x 5 classes) per-cell eps-MSE max rel err {rel:.2e}; predictions rel-L2 (worst class) {pr:.2e}")
+    assert rel < 1e-4, rel
+    assert pr < 5e-5, pr
+    assert got_l.cpu().tolist() == ref_l.tolist()
+    plan = next(iter(dc._score_plans.values()))["plan"]
+    names = [mt["name"] for mt in plan.pb.meta]
+    assert plan.n_cls == 5 and plan.pb.n["unit"] == 5 * plan.pb.n["bj"]
+    assert any(n.endswith(".conv1s") for n in names)                     # class-shared skip halves are in play on this net too
+    assert "down_blocks.4.resnets.3.conv1" in names
+
+
+def test_cfg3_full_grid_properties_at_bench_size():
+    """BASELINE config 3 at the size `bench.py` times (CheXpert-DWT UNet, 2 classes x 100 trials, bf16, philox noise, 2 images = 400
+    unit-forwards of 176 GFLOP) through the oracle-free properties of `test_cfg2_full_grid_properties_at_bench_size`: a repeated
+    call is bit-identical, the label is the arg-min of the mean error, per-cell errors do not depend on the launch size, and a
+    two-stage schedule scores exactly the cells the reference's pruning (:718-721) leaves, with the same per-cell errors."""
+    kw = dca.chexpert_dwt_unet_kwargs()
+    torch.manual_seed(91)
+    m = dca.UNetCondition2D(**kw)
+    _randomise_vectors(m)
+    cfg = dict(CFG2, classes=2, evaluation_per_stage=[100], image_size=128, noise_d=128, compute_dtype="bf16")
+    dc = dca.DiffusionClassifier(m, dca.Config(**cfg)).to(DEV)
+    torch.manual_seed(92)
+    x0 = (torch.rand(2, 3, 256, 256) * 2 - 1).to(DEV)
+    x = dca.wavelet_dec_2(x0, scale=0.5)
+    t = torch.rand(100, 2)
+    l1, e1 = dc.classify(x, t=t, rng="philox", seed=9, return_errors=True)
+    l2, e2 = dc.classify(x, t=t, rng="philox", seed=9, return_errors=True)
+    assert e1.shape == (2, 2, 100) and torch.isfinite(e1).all()
+    assert torch.equal(e1, e2) and torch.equal(l1, l2)
+    assert l1.cpu().tolist() == e1.cpu().mean(2).argmin(1).tolist()
+    dc.config.units_per_launch = 2 * 37                                   # 200 pairs in micro-batches of 37: ragged last launch
+    l3, e3 = dc.classify(x, t=t, rng="philox", seed=9, return_errors=True)
+    assert torch.equal(e1, e3) and torch.equal(l1, l3)
+    dc.config.units_per_launch = None
+    dc.config.n_stages, dc.config.evaluation_per_stage, dc.config.n_keep_per_stage = 2, [20, 100], [1, 1]
+    lb, eb = dc.classify(x, t=t, rng="philox", seed=9, return_errors=True)
+    e1c, ebc = e1.cpu(), eb.cpu()
+    assert torch.equal(ebc[:, :, :20], e1c[:, :, :20])
+    keep = e1c[:, :, :20].mean(2).argmin(1)
+    kept = torch.zeros(2, 2, dtype=torch.bool)
+    kept[torch.arange(2), keep] = True
+    assert torch.equal(torch.isfinite(ebc[:, :, 20:]).all(2), kept) and torch.equal(torch.isfinite(ebc[:, :, 20:]).any(2), kept)
+    assert torch.equal(ebc[:, :, 20:][kept], e1c[:, :, 20:][kept])
+    assert lb.cpu().tolist() == keep.tolist()
+
+
 def _dit_b4(seed, nclass_rows=10):
     kw = dict(dca.chexpert_dit_b4_kwargs(True), num_embeds_ada_norm=nclass_rows)
     torch.manual_seed(seed)
@@ -214,11 +291,13 @@ def test_cfg5_dit_b4_full_depth_f16_forward_and_classify():
     torch.manual_seed(73)
     xx = torch.rand(BS, 12, 128, 128) * 2 - 1
     t, eps = torch.rand(T, BS), torch.randn(T, BS, 12, 128, 128)
-    ref_l, ref_e = oc.classify(xx, t=t, eps=eps, return_errors=True)
+    ref_l, ref_e, ref_p = oc.classify(xx, t=t, eps=eps, return_errors=True, return_preds=True)
     got_l, got_e = dc.classify(xx.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
     rel = ((got_e - ref_e).abs() / ref_e).max().item()
-    print(f"cfg5 DiT-B/4 f16 classify per-cell eps-MSE max rel err: {rel:.2e}")
+    pr = pred_rel_l2(hip_preds(dc, T, BS), ref_p)
+    print(f"cfg5 DiT-B/4 f16 classify per-cell eps-MSE max rel err: {rel:.2e}; predictions rel-L2 (worst sample) {pr:.2e}")
     assert rel < 5e-3, rel
+    assert pr < 6e-3, pr
     gap = abs(ref_e.mean(2)[0, 0] - ref_e.mean(2)[0, 1]) / ref_e.mean(2).min()
     if gap > 2 * rel:
         assert got_l.cpu().tolist() == ref_l.tolist()
@@ -244,11 +323,14 @@ def test_cfg3_inputs_are_the_haar_transform_of_the_image():
     assert x_hip.shape == (1, 12, 128, 128)
     assert (x_hip.cpu() - x_ref).abs().max().item() < 2e-6
     t, eps = torch.rand(1, 1), torch.randn(1, 1, 12, 128, 128)
-    ref_l, ref_e = oc.classify(x_ref, t=t, eps=eps, return_errors=True)
-    got_l, got_e = dc.to(DEV).classify(x_hip, t=t, eps=eps.to(DEV), return_errors=True)
+    ref_l, ref_e, ref_p = oc.classify(x_ref, t=t, eps=eps, return_errors=True, return_preds=True)
+    dc = dc.to(DEV)
+    got_l, got_e = dc.classify(x_hip, t=t, eps=eps.to(DEV), return_errors=True)
     rel = ((got_e - ref_e).abs() / ref_e).max().item()
-    print(f"cfg3 bf16 classify (1 trial x 2 classes) per-cell eps-MSE max rel err: {rel:.2e}")
+    pr = pred_rel_l2(hip_preds(dc, 1, 1), ref_p)
+    print(f"cfg3 bf16 classify (1 trial x 2 classes) per-cell eps-MSE max rel err: {rel:.2e}; predictions rel-L2 (worst sample) {pr:.2e}")
     assert rel < 2e-2, rel
+    assert pr < 2e-2, pr
 
 
 def test_cfg2_full_grid_properties_at_bench_size():

@@ -36,6 +36,26 @@ def test_product_loop_matches_reference_goldens(name):
     np.testing.assert_array_equal(out2.numpy(), g["out"])
 
 
+def test_simulated_rank_scores_exactly_that_ranks_share():
+    """bench.py --simulate-rank r/N (config key `simulate_rank`): without a process group the call evaluates the (trial, image)
+    pairs dist.local_pairs deals to rank r — those cells equal the full run's, every other cell stays +inf."""
+    from diffusion_classifier_amd import dist as D
+    g, cfg = load_case("1stage_eps")
+    x, t, eps = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["eps"])
+    T, BS = t.shape
+    for r, n in ((0, 3), (2, 3), (1, 2)):
+        dc = dca.DiffusionClassifier(standin_from(g, cfg), dca.Config(**dict(cfg, simulate_rank=(r, n))))
+        dc.encoder.weight.data.copy_(torch.from_numpy(g["encoder.weight"]))
+        _, err = dc.classify(x, t=t, eps=eps, return_errors=True)
+        mine = torch.zeros(BS, T, dtype=torch.bool)
+        for j, b in D.local_pairs(0, T, BS, r, n):
+            mine[b, j] = True
+        fin = torch.isfinite(err)
+        assert torch.equal(fin, mine[:, None, :].expand_as(fin))
+        # (sub-batches of a trial on the CPU stand-in: torch's kernels differ in the last bit with the batch size)
+        np.testing.assert_allclose(err[fin].numpy(), torch.from_numpy(g["errors"])[fin].numpy(), rtol=1e-6)
+
+
 def test_schedule_matches_reference_goldens():
     g = np.load(os.path.join(ROOT, "tests", "golden", "schedules.npz"))
     t = torch.from_numpy(g["t"])
