@@ -358,8 +358,10 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && use_xreg) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
     else if (bn == 128 && !use_v1) {
-      static const char* const shapes[3] = {"igemm_pipe<%s,128x128,2st>", "igemm_pipe<%s,256x128,3st>", "igemm_pipe<%s,256x256,2st>"};
-      snprintf(name, sizeof(name), shapes[dc_igemm_pipe_shape(a)], dn);
+      static const char* const shapes[4] = {"igemm_pipe<%s,128x128,2st>", "igemm_pipe<%s,256x128,3st>", "igemm_pipe<%s,256x256,2st>",
+                                            "igemm_wide8<%s,256x256>"};
+      const int shp = dc_igemm_pipe_shape(a);
+      snprintf(name, sizeof(name), shapes[shp == 2 && dc_igemm_wide8_enabled() ? 3 : shp], dn);
     }
     else snprintf(name, sizeof(name), "igemm<%s,128x%d>", dn, bn);
     *variant = name;

@@ -141,6 +141,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 // defined in igemm_pipe.hip; returns DC_ERR_UNSUPPORTED-free status (always handles tile_n == 128)
 int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s);
 int dc_igemm_pipe_shape(const IgemmArgs& a);   // 0: 128x128, 1: 256x128, 2: 256x256 tile
+// igemm_wide.hip: the 256 x 256 tile on the 8-phase main loop (DCAMD_WIDE_OLD keeps the 2-stage loop of igemm_pipe.hip: A/B runs)
+int dc_igemm_launch_wide8(const IgemmArgs& a, int dtype, hipStream_t s);
+bool dc_igemm_wide8_enabled();
 // conv3_halo.hip
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype);
 bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype);   // fused GroupNorm prologue possible

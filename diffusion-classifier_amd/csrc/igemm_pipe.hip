@@ -336,6 +336,10 @@ int dc_igemm_pipe_shape(const IgemmArgs& a) {
   return 1;
 }
 
+bool dc_igemm_wide8_enabled() {
+  return getenv("DCAMD_WIDE_OLD") == nullptr;      // read per call (~0.1 us): tools/bench_wide_ab.py alternates the two loops inside one process
+}
+
 // four-phase upsample conv on the tap-gather kernel (sources smaller than 8x8): a0 as dc_igemm received it (upsampled extents)
 int dc_igemm_launch_pipe_up4(const IgemmArgs& a0, int dtype, hipStream_t s) {
   IgemmArgs a = a0;
@@ -364,6 +368,7 @@ int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s) {
     return launch_pipe<float, 128, 2, 1, -1, false>(a, s);
   }
   if (shape == 2) {
+    if (dc_igemm_wide8_enabled()) return dc_igemm_launch_wide8(a, dtype, s);
     if (dtype == DC_BF16) return launch_wide<__bf16>(a, s);
     if (dtype == DC_F16) return launch_wide<_Float16>(a, s);
     return launch_wide<float>(a, s);

@@ -70,5 +70,5 @@ def test_bench_harness_with_three_ranks_rehearsed_on_one_gpu(tmp_path):
     assert len(lines) == 1, r.stdout[-1000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["value"] > 0 and d["config"]["parallelism"] == "grid-shard x3" and d["config"]["images_per_step"] == 24
+    assert d["value"] > 0 and d["config"]["parallelism"].startswith("grid-shard x3") and d["config"]["images_per_step"] == 24
     assert "REHEARSAL" in d["data"] and "roofline" in d and "cpu_baseline" not in d
