@@ -272,7 +272,16 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   a.tiles_m = (a.M + 127) / 128;
   a.tiles_n = dc_igemm_cout_pad(p->Cout, bn) / bn;
   static const bool no_nfast = getenv("DCAMD_NO_NFAST") != nullptr;
-  a.n_fast = (!no_nfast && a.tiles_n > 1 && (long long)dc_igemm_cout_pad(p->Cout, bn) * a.Ktot * dc_dtype_size(p->dtype) <= (2 << 20)) ? 1 : 0;
+  {
+    // N fastest when the whole weight matrix can stay in an XCD's L2 next to the activation stream (<= 2 MiB), and for 1-tap GEMMs
+    // up to DCAMD_NFAST_GEMM_BYTES (default 16 MiB): there the activation panel of an M tile (rows x K) is the big operand — with
+    // M fastest it is re-fetched from HBM once per N panel (DiT-B/4 qkv: 9 x 786 MB per launch, the GEMM ran HBM-bound), with N
+    // fastest the N tiles of an M tile run side by side on one XCD and share it in L2, while the weights come back from L2 / MALL
+    const char* e = getenv("DCAMD_NFAST_GEMM_BYTES");        // read per call: tools/bench_wide_ab.py --order alternates it in one process
+    const long long gemm_cap = e ? atoll(e) : (16LL << 20);
+    const long long wbytes = (long long)dc_igemm_cout_pad(p->Cout, bn) * a.Ktot * dc_dtype_size(p->dtype);
+    a.n_fast = (!no_nfast && a.tiles_n > 1 && (wbytes <= (2 << 20) || (p->taps == 1 && wbytes <= gemm_cap))) ? 1 : 0;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // tile_n 128: the LDS-DMA pipelined 256x128 kernel (igemm_pipe.hip).  DCAMD_IGEMM_V1=1 selects the
   // register-staged 128x128 kernel instead (A/B measurements; same results bit for bit).

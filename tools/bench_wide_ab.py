@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--order", action="store_true",
+                    help="A/B the TILE ORDER of the new loop instead: 'old' = M fastest (DCAMD_NFAST_GEMM_BYTES=0), 'new' = N fastest (default)")
     args = ap.parse_args()
     dt = E.DT[args.dtype]
     td = E.TORCH_DT[dt]
@@ -51,7 +53,12 @@ def main():
         outs = {}
         for rnd in range(args.rounds + 1):                 # round 0 = warm-up
             for arm in ("old", "new"):
-                if arm == "old":
+                if args.order:
+                    if arm == "old":
+                        os.environ["DCAMD_NFAST_GEMM_BYTES"] = "0"
+                    else:
+                        os.environ.pop("DCAMD_NFAST_GEMM_BYTES", None)
+                elif arm == "old":
                     os.environ["DCAMD_WIDE_OLD"] = "1"
                 else:
                     os.environ.pop("DCAMD_WIDE_OLD", None)
@@ -72,6 +79,7 @@ def main():
               f"  bit-identical={same}  [{names['old']} | {names['new']}]", flush=True)
         del x, Wp, r, out
     os.environ.pop("DCAMD_WIDE_OLD", None)
+    os.environ.pop("DCAMD_NFAST_GEMM_BYTES", None)
 
 
 if __name__ == "__main__":
