@@ -19,6 +19,29 @@ int dc_check_launch(const char* what);
 #define DC_REQUIRE(cond, code, ...) \
   do { if (!(cond)) { dc_set_error(__VA_ARGS__); return (code); } } while (0)
 
+// ---- in-kernel clock stamps (diagnostic builds only: -DDC_CLOCK_STAMPS, tools/clock_probe.py) ------------------------------
+// MI355X_MICROARCH.md "DVFS give-back" item 6: the clock a kernel actually holds is (delta s_memtime) / (delta s_memrealtime) x 100 MHz,
+// stamped once around its main loop.  DC_CLOCK(k), k = 0 before / 1 after the loop, by thread 0 of every workgroup, into a buffer of
+// its own (4 x u64 per workgroup) that nothing else reads; no stamp is compiled into the shipped library.
+#ifdef DC_CLOCK_STAMPS
+#define DC_CLOCK_DECL(tu)                                                                                                      \
+  static __device__ unsigned long long* g_clk_buf;                                                                             \
+  extern "C" void dc_debug_set_clk_##tu(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clk_buf), &p, sizeof(p)); }
+#define DC_CLOCK(k)                                                                                                            \
+  do {                                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    if (threadIdx.x == 0 && g_clk_buf) {                                                                                       \
+      g_clk_buf[(size_t)blockIdx.x * 4 + 2 * (k)] = __builtin_amdgcn_s_memtime();                                              \
+      g_clk_buf[(size_t)blockIdx.x * 4 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();                                      \
+    }                                                                                                                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+  } while (0)
+#else
+#define DC_CLOCK_DECL(tu)
+#define DC_CLOCK(k) do {} while (0)
+#endif
+
 // ---- element traits ---------------------------------------------------------------
 template <typename T> struct Elem;
 

@@ -37,6 +37,7 @@ extern "C" void dc_debug_set_stamps(unsigned long long* p) { (void)hipMemcpyToSy
 
 static __device__ chunk16 g_zero_page[16];   // per translation unit (no device-side linking)
 #include "conv3_halo.h"
+DC_CLOCK_DECL(conv3_halo)
 
 // GN: fused GroupNorm(+SiLU) prologue compiled in (opt-in variant; the plain kernel carries none of its code)
 // NTAP: 9 = the 3x3 conv.  4 = one PHASE of "nearest-2x upsample, then 3x3 conv" (dc_igemm_params.up4): output pixel
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     for (int i = 0; i < NXL; ++i) xform(0, i);
   }
   constexpr int FLY = (PD - 1) * WLD;                // W(s+1) .. W(s+PD-1)
+  DC_CLOCK(0);
   for (int cc = 0; cc < nchunks; ++cc) {
     // "has_next": another X chunk and more W groups follow this chunk — the next 3x3 chunk, or the first chunk of the
     // 1x1 side source, whose W2 tiles simply continue the W stream (s >= NS)
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     if constexpr (NTAP == 9) { step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{}); }
   }
 
+  DC_CLOCK(1);
   // ---- 1x1 side source (a ResNet's conv_shortcut folded into its conv2): nx steps of ONE tap (the centre) each.  X2(0)
   // and W2(0 .. PD-1) were issued inside the last 3x3 chunk; a step needs a fresh halo chunk per 32 MFMAs, so from the second
   // step on the loads of the previous step are simply drained (vmcnt 0): ~2 k exposed cycles per step, against the whole

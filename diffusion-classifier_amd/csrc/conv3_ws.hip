@@ -30,6 +30,7 @@ extern "C" void dc_debug_set_ws_stamps(unsigned long long* p) { (void)hipMemcpyT
 #define DC_STAMP(k) do {} while (0)
 #endif
 #include "conv3_halo.h"
+DC_CLOCK_DECL(conv3_ws)
 
 struct WsCfg {
   static constexpr int NT = 512, NTL = 256;                 // threads; threads per team
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     }
   };
   DC_STAMP(1);
+  DC_CLOCK(0);
   for (int cc = 0; cc < nchunks; ++cc) {
     const int s0c = cc * NTAP;
     const char* Xb = smem + (cc & 1) * Cfg::XBUF;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     };
     step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
   }
+  DC_CLOCK(1);
   {
     const int NSm = nchunks * NTAP;
     for (int e = 0; e < nx; ++e) {

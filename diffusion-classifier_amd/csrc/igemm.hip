@@ -325,9 +325,14 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     if (up4_halo) return dc_conv3_up4_launch(a, p->dtype, p->n_img, s);
     return dc_igemm_launch_pipe_up4(a, p->dtype, s);
   }
+  // wave-specialised halo conv: takes the fused GroupNorm prologue (also together with the 1x1 side source / a residual); DCAMD_WS_PLAIN
+  // routes the plain one-image-per-patch convs there too (A/B of the structure alone)
+  static const bool ws_plain = getenv("DCAMD_WS_PLAIN") != nullptr;
+  const bool ws_ok = halo_ok && !env_v1 && dc_conv3_ws_ok(a, p->dtype) && !dc_conv3_thin_applicable(a, p->dtype);
+  const bool use_ws = ws_ok && (a.gn_scale || ws_plain);
   if (a.src2) {
     const int bke64 = 64 / dc_dtype_size(p->dtype);
-    const bool side_ok = halo_ok && !a.gn_scale && !a.upsample && a.W2 && a.C2 >= 2 * bke64 && a.C2 % bke64 == 0 && a.ld2 % epc == 0 &&
+    const bool side_ok = halo_ok && (!a.gn_scale || ws_ok) && !a.upsample && a.W2 && a.C2 >= 2 * bke64 && a.C2 % bke64 == 0 && a.ld2 % epc == 0 &&
                          (((uintptr_t)a.src2 | (uintptr_t)a.W2) & 15) == 0 && lane_epi_ok;
     if (!side_ok) {
       if (variant) { *variant = "side-source-unsupported"; return DC_ERR_UNSUPPORTED; }
@@ -336,7 +341,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     }
   }
   const bool thin_gn = a.gn_scale && !env_v1 && dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;   // conv_out: normalised in the halo
-  if (a.gn_scale && !thin_gn && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
+  if (a.gn_scale && !thin_gn && !ws_ok && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
     if (variant) { *variant = "gn-not-fusable"; return DC_ERR_UNSUPPORTED; }
     dc_set_error("dc_igemm: gn_scale/gn_shift given but this problem cannot take the fused GroupNorm prologue (see dc_igemm_gn_fusable)");
     return DC_ERR_UNSUPPORTED;
@@ -364,7 +369,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   if (variant) {
     static thread_local char name[64];
     if (thin) { snprintf(name, sizeof(name), "conv3_thin<%s>", dn); *variant = name; return DC_OK; }
-    if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
+    if (use_ws) snprintf(name, sizeof(name), a.gn_scale ? "conv3_ws<%s,gn>" : "conv3_ws<%s>", dn);
+    else if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && use_xreg) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
     else if (bn == 128 && !use_v1) {
       static const char* const shapes[4] = {"igemm_pipe<%s,128x128,2st>", "igemm_pipe<%s,256x128,3st>", "igemm_pipe<%s,256x256,2st>",
@@ -377,6 +383,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     return DC_OK;
   }
   if (thin) return dc_conv3_thin_launch(a, p->dtype, p->n_img, s);
+  if (use_ws) return dc_conv3_ws_launch(a, p->dtype, p->n_img, s);
   if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) return dc_conv3_halo_launch(a, p->dtype, p->n_img, s);
   if (bn == 128 && !use_v1 && use_xreg) return dc_igemm_xreg_launch(a, p->dtype, s);
   if (bn == 128 && !use_v1) return dc_igemm_launch_pipe(a, p->dtype, s);

@@ -151,6 +151,9 @@ int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s
 bool dc_conv3_up4_applicable(const IgemmArgs& a, int dtype);   // upsample + 3x3 conv as four 2x2-tap phases
 int dc_conv3_up4_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);
 int dc_igemm_launch_pipe_up4(const IgemmArgs& a, int dtype, hipStream_t s);   // the same on the tap-gather kernel (sources < 8x8)
+// conv3_ws.hip: wave-specialised halo conv (loader / transform waves + MFMA waves) with the input's GroupNorm(+SiLU) fused in
+bool dc_conv3_ws_ok(const IgemmArgs& a, int dtype);
+int dc_conv3_ws_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);
 // igemm_xreg.hip: activation-stationary GEMM for K <= 256 (16-bit, 1 tap)
 bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype);
 int dc_igemm_xreg_launch(const IgemmArgs& a, int dtype, hipStream_t s);

@@ -42,6 +42,7 @@
 #include "igemm_epilogue.h"
 
 static __device__ chunk16 g_zero_page_w[16];
+DC_CLOCK_DECL(igemm_wide)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wide8_kernel(const IgemmArgs a) 
                                  "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[1][2]), "+v"(wf[1][3]))
 #define W8_WAIT_X(XF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XF[0][0]), "+v"(XF[0][1]), "+v"(XF[1][0]), "+v"(XF[1][1]))
 
+  DC_CLOCK(0);
   for (int kt = 0; kt < nk; ++kt) {
     const uint32_t bufo = (uint32_t)(kt & 1) * BUF;
     // ---- q0: W0 x X0.  X0's four reads go first and are retired before the barrier: X0's slot is re-staged in q1 ----
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wide8_kernel(const IgemmArgs a) 
 #undef W8_READ_W
 #undef W8_WAIT_W
 #undef W8_WAIT_X
+  DC_CLOCK(1);
   if (wave < 4) __builtin_amdgcn_s_barrier();          // group B arrived once more in front of the loop
 
   // ---- epilogue: straight from the accumulators (igemm_epilogue.h), no LDS, no barrier ----

@@ -18,6 +18,7 @@
 // landed — the next PD slices need no wait, and by the time one is needed the stores are three slices old.
 #include <stdlib.h>
 #include "igemm_epilogue.h"
+DC_CLOCK_DECL(igemm_xreg)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
   for (int sub = 0; sub < 2; ++sub) woff[sub] = sbase + lds_off(wn * 64 + lr, sub * 4 + lq);
 
   int q = 0;
+  DC_CLOCK(0);       // around the whole N-tile loop: K loops and the (VALU-heavy) epilogues between them
   for (int nt = 0; nt < a.tiles_n; ++nt) {
     // GEGLU: this N tile's bias (8 value-row and 8 gate-row entries per lane) is fetched HERE, ahead of the K loop: the epilogue
     // of the short-K projection ran once per 96 MFMAs and paid a global-load latency in front of its VALU work every time.
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
       epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, nt, wn, lq, sf, sl_, rowfn, drain);
     }
   }
+  DC_CLOCK(1);
 }
 
 bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype) {

@@ -214,6 +214,15 @@ class PlanBuilder:
                           tile_n=tile_n, out=fake, out_dtype=src0.dt if out_dt is None else out_dt, out_ld=Cout)
         return bool(L.lib().dc_igemm_gn_fusable(p))
 
+    def gn_ws_ok(self, x, Cout):
+        """Would a 3x3 stride-1 conv of x with a fused GroupNorm prologue run on the wave-specialised halo kernel (conv3_ws.hip: the
+        transform is done by loader waves, not in the MFMA waves' stream)?  Asked through dc_igemm_variant."""
+        fake = 1 << 20
+        p = L.IgemmParams(dtype=x.dt, taps=9, stride=1, upsample=0, n_img=self.n[x.dom], Hin=x.H, Win=x.W, Hout=x.H, Wout=x.W,
+                          src0=fake, C0=x.C, ld0=x.ld, W=fake, Cout=Cout, tile_n=128, out=fake, out_dtype=x.dt, out_ld=Cout,
+                          gn_scale=fake, gn_shift=fake, gn_silu=1)
+        return L.lib().dc_igemm_variant(p).decode().startswith("conv3_ws")
+
     def groupnorm_stats(self, name, x0, gamma, beta, groups, eps, x1=None):
         """Statistics-only GroupNorm: returns the per-(sample, channel) scale / shift tensors for a fused conv prologue."""
         dom = self._dom(x0, x1)
@@ -643,6 +652,9 @@ class UNetPlan:
         use_up4 = os.environ.get("DCAMD_NO_UP4") is None
         fold_ln = os.environ.get("DCAMD_NO_LN_FOLD") is None
         fold_ln_qkv = os.environ.get("DCAMD_LN_FOLD_QKV") is not None
+        # GroupNorm(+SiLU) applied by the consuming 3x3 conv's loader waves (conv3_ws.hip) from the producer's quad records: no
+        # GroupNorm launch, the normalised tensor never exists (DCAMD_NO_GN_WS: the GroupNorm pass + the plain conv, for A/B runs)
+        fuse_ws = os.environ.get("DCAMD_NO_GN_WS") is None and use_qs and not fuse_gn
         cfg = model.config
         dev = device or weights.dev
         dt = weights.dt
@@ -704,6 +716,17 @@ class UNetPlan:
         pc.finalize(keep_alive=list(cv_t.values()))
         cvec = {k: pb.external(k + ".cvec", pc.tensor_view(t).view(n_ctx, -1), "ctx", 1, 1, t.C, L.DC_F32) for k, t in cv_t.items()}
 
+        def gn_conv3(gname, cname, x, gamma, beta, groups, Wp, Cout, **kw):
+            """GroupNorm + SiLU of the single-source tensor x, then a 3x3 conv of it (bias / row vector / residual / side source
+            in kw).  One launch where the wave-specialised conv can normalise its own input (affine from the quad records x's
+            producer wrote: no pass over x at all); else the GroupNorm pass and the plain conv."""
+            dom = pb._dom(x, kw.get("rowvec"), kw.get("residual"), kw["side"][0] if kw.get("side") else None)
+            if fuse_ws and dom == x.dom and pb.qstats_ok(x, None, groups, dom) and pb.gn_ws_ok(x, Cout):
+                aff = pb.groupnorm_stats(gname, x, gamma, beta, groups, eps)
+                return pb.igemm(cname, x, Wp, Cout, taps=9, gn=(aff[0], aff[1], True), **kw)
+            y = pb.groupnorm(gname, x, gamma, beta, groups, eps, True)
+            return pb.igemm(cname, y, Wp, Cout, taps=9, **kw)
+
         def resnet(key, x0, x1=None):
             Cout = P[key + ".conv1.b"].shape[0]
             tvec = tproj.view(weights.tproj_off[key], Cout)
@@ -725,20 +748,22 @@ class UNetPlan:
                 cpg = (Ca + Cb) // G
                 weights.split_resnet(key, Ca)
                 g1, b1 = P[key + ".norm1.g"], P[key + ".norm1.b"]
-                ys = pb.groupnorm(key + ".gn1s", x1, pb.const(g1[Ca:]), pb.const(b1[Ca:]), Cb // cpg, eps, True)
-                ts = pb.igemm(key + ".conv1s", ys, pb.const(P[key + ".conv1.wb"]), Cout, taps=9)
-                yh = pb.groupnorm(key + ".gn1", x0, pb.const(g1[:Ca]), pb.const(b1[:Ca]), Ca // cpg, eps, True)
-                h = pb.igemm(key + ".conv1", yh, pb.const(P[key + ".conv1.wa"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
-                             rowvec=tvec, residual=ts, qstats=use_qs)
+                ts = gn_conv3(key + ".gn1s", key + ".conv1s", x1, pb.const(g1[Ca:]), pb.const(b1[Ca:]), Cb // cpg,
+                              pb.const(P[key + ".conv1.wb"]), Cout)
+                h = gn_conv3(key + ".gn1", key + ".conv1", x0, pb.const(g1[:Ca]), pb.const(b1[:Ca]), Ca // cpg,
+                             pb.const(P[key + ".conv1.wa"]), Cout, bias=pb.const(P[key + ".conv1.b"]), rowvec=tvec, residual=ts, qstats=use_qs)
+            elif x1 is None:
+                h = gn_conv3(key + ".gn1", key + ".conv1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G,
+                             pb.const(P[key + ".conv1.w"]), Cout, bias=pb.const(P[key + ".conv1.b"]), rowvec=tvec, qstats=use_qs)
             else:
                 h = pb.groupnorm(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, True, x1=x1)
                 h = pb.igemm(key + ".conv1", h, pb.const(P[key + ".conv1.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
                              rowvec=tvec, qstats=use_qs)
             fuse2 = fuse_gn and pb.gn_fusable(h, None, Cout)
+            h_raw = h                  # conv1's output: conv2 normalises it itself where gn_conv3 can (norm2 + SiLU)
+            n2g, n2b = pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"])
             if fuse2:
-                aff2 = pb.groupnorm_stats(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps)
-            else:
-                h = pb.groupnorm(key + ".gn2", h, pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"]), G, eps, True)
+                aff2 = pb.groupnorm_stats(key + ".gn2", h, n2g, n2b, G, eps)
             # conv_shortcut folded into conv2: the 1x1 over the raw input becomes extra K chunks of conv2's own MFMA loop
             # (conv3_halo side source) — no shortcut launch, no shortcut tensor written and read back
             fold = (fold_short and not fuse2 and key + ".conv_shortcut.w" in P and (x1 is None or split)
@@ -748,8 +773,8 @@ class UNetPlan:
                     P[key + ".conv2.bs"] = (P[key + ".conv2.b"] + P[key + ".conv_shortcut.b"]).contiguous()
                 ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout) if split else None
                 w2 = P[key + ".conv_shortcut.wa"] if split else P[key + ".conv_shortcut.w"]
-                return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.bs"]),
-                                residual=ss, side=(x0, pb.const(w2)), qstats=use_qs)
+                return gn_conv3(key + ".gn2", key + ".conv2", h_raw, n2g, n2b, G, pb.const(P[key + ".conv2.w"]), Cout,
+                                bias=pb.const(P[key + ".conv2.bs"]), residual=ss, side=(x0, pb.const(w2)), qstats=use_qs)
             if split and key + ".conv_shortcut.w" in P:
                 ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout)
                 sc = pb.igemm(key + ".short", x0, pb.const(P[key + ".conv_shortcut.wa"]), Cout,
@@ -760,8 +785,11 @@ class UNetPlan:
             else:
                 assert x1 is None
                 sc = x0
-            return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.b"]),
-                            residual=sc, gn=(aff2[0], aff2[1], True) if fuse2 else None, qstats=use_qs)
+            if fuse2:
+                return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.b"]),
+                                residual=sc, gn=(aff2[0], aff2[1], True), qstats=use_qs)
+            return gn_conv3(key + ".gn2", key + ".conv2", h_raw, n2g, n2b, G, pb.const(P[key + ".conv2.w"]), Cout,
+                            bias=pb.const(P[key + ".conv2.b"]), residual=sc, qstats=use_qs)
 
         def transformer(key, x):
             Cc = x.C

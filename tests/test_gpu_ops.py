@@ -756,6 +756,90 @@ def test_thin_conv_with_groupnorm_from_quad_statistics(dt, shape):
     assert maxrel(o, ref) < {L.DC_F32: 3e-5, L.DC_BF16: 1.5e-2, L.DC_F16: 3e-3}[dt], maxrel(o, ref)
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("case", ["c128_32x32_res", "c128_32x32_side", "c256to128_16x16", "two_ntiles_64x32", "maps_plain"])
+def test_wave_specialised_conv_with_fused_groupnorm_is_bit_identical(dt, case):
+    """GroupNorm + SiLU -> 3x3 conv as ONE launch (conv3_ws.hip: loader waves normalise each landed halo chunk in place from the
+    producer's quad records, MFMA waves only multiply) against the two launches it replaces (dc_groupnorm with the same quad records,
+    then conv3_halo): outputs AND the output's own quad records bit for bit, with a bias, a per-sample row vector, a residual read
+    through a map, the folded 1x1 side source, several N tiles, sample maps; and torch within the dtype's tolerance."""
+    torch.manual_seed(35)
+    n, H, W, C, Co, side, res, maps = {"c128_32x32_res": (5, 32, 32, 128, 128, 0, True, False),
+                                       "c128_32x32_side": (3, 32, 32, 128, 128, 128, True, False),
+                                       "c256to128_16x16": (6, 16, 16, 256, 128, 0, False, False),
+                                       "two_ntiles_64x32": (2, 64, 32, 128, 256, 64, True, False),
+                                       "maps_plain": (7, 16, 16, 128, 128, 0, True, True)}[case]
+    g = E.bke(dt)
+    q = lambda t: t.to(TD[dt]).float()
+    lib = L.lib()
+    n_src = 3 if maps else n                  # sample maps: 7 output samples read 3 source samples (class-shared trunk -> per-unit layer)
+    # producer: a 3x3 conv that also writes the quad statistics of its output h
+    x0 = q(torch.randn(n_src, 2 * g, H, W))
+    wp_ = q(torch.randn(C, 2 * g, 3, 3) / (3 * (2 * g) ** 0.5))
+    a0, Wpp = nhwc(x0, dt), E.pack_conv3x3(wp_, dt, DEV)
+    h = torch.empty(n_src, H, W, C, dtype=TD[dt], device=DEV)
+    kw = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n_src, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=2 * g, W=ptr(Wpp), Cout=C,
+              tile_n=128, out=ptr(h), out_dtype=dt, out_ld=C)
+    parts = lib.dc_igemm_qstats_parts(L.IgemmParams(**kw))
+    assert parts > 0
+    qs = torch.zeros(n_src, parts, C // 4, 2, device=DEV)
+    run_igemm(qstats=ptr(qs), **kw)
+    gamma, beta = (torch.randn(C) * 0.5 + 1).to(DEV), torch.randn(C).to(DEV)
+    splits = lib.dc_groupnorm_splits(n_src, H * W, C)
+    ws = torch.zeros(lib.dc_groupnorm_ws_floats(n_src, 32, splits), device=DEV)
+    gk = dict(x=ptr(h), dtype=dt, out_dtype=dt, n=n_src, HW=H * W, C=C, C1=0, groups=32, splits=splits, eps=1e-5, gamma=ptr(gamma), beta=ptr(beta),
+              ws=ptr(ws), qstats=ptr(qs), qparts=parts)
+    y = torch.empty_like(h)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(y=ptr(y), silu=1, **gk), L.stream_ptr()), "gn")
+    sc, sh = torch.zeros(n_src, C, device=DEV), torch.zeros(n_src, C, device=DEV)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(y=None, silu=0, out_scale=ptr(sc), out_shift=ptr(sh), **gk), L.stream_ptr()), "gn affine")
+    # the consumer conv
+    w = q(torch.randn(Co, C, 3, 3) / (3 * C ** 0.5))
+    b, rv = torch.randn(Co).to(DEV), torch.randn(n, Co).to(DEV)
+    Wo = E.pack_conv3x3(w, dt, DEV)
+    smap = torch.tensor([i % n_src for i in range(n)], dtype=torch.int32, device=DEV) if maps else None
+    r = torch.randn(n_src if maps else n, H, W, Co, device=DEV).to(TD[dt]) if res else None
+    xs = q(torch.randn(n_src if maps else n, side, H, W)) if side else None
+    ws2 = q(torch.randn(Co, side) / side ** 0.5) if side else None
+    ck = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, C0=C, map0=ptr(smap), W=ptr(Wo), Cout=Co, tile_n=128,
+              bias=ptr(b), rowvec=ptr(rv), rowvec_ld=Co, out_dtype=dt, out_ld=Co)
+    keep = []
+    if res:
+        ck.update(residual=ptr(r), res_map=ptr(smap), res_dtype=dt, res_ld=Co)
+    if side:
+        a2, W2 = nhwc(xs, dt), E.pack_matrix(ws2, dt, DEV)
+        keep += [a2, W2]
+        ck.update(src2=ptr(a2), map2=ptr(smap), W2=ptr(W2), C2=side, ld2=side)
+    parts_o = lib.dc_igemm_qstats_parts(L.IgemmParams(src0=ptr(y), out=ptr(y), **ck))
+    assert parts_o > 0
+    o_ref = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    q_ref = torch.full((n, parts_o, Co // 4, 2), float("nan"), device=DEV)
+    pu = L.IgemmParams(src0=ptr(y), out=ptr(o_ref), qstats=ptr(q_ref), **ck)
+    assert lib.dc_igemm_variant(pu).decode().startswith("conv3_halo")
+    L.check(lib.dc_igemm(pu, L.stream_ptr()), "GroupNorm kernel + halo conv")
+    # the affine of a mapped source sample lives in the conv's own sample index space: gather it like the engine's domains do
+    scn, shn = (sc[smap.long()].contiguous(), sh[smap.long()].contiguous()) if maps else (sc, sh)
+    o = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    q_o = torch.full((n, parts_o, Co // 4, 2), float("nan"), device=DEV)
+    pf = L.IgemmParams(src0=ptr(h), out=ptr(o), qstats=ptr(q_o), gn_scale=ptr(scn), gn_shift=ptr(shn), gn_silu=1, **ck)
+    assert lib.dc_igemm_gn_fusable(pf) == 1 and lib.dc_igemm_variant(pf).decode() == "conv3_ws<%s,gn>" % {L.DC_F32: "f32", L.DC_BF16: "bf16", L.DC_F16: "f16"}[dt]
+    L.check(lib.dc_igemm(pf, L.stream_ptr()), "wave-specialised conv with fused GroupNorm")
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all() and torch.isfinite(q_o).all()
+    if H * W * C * (4 if dt == L.DC_F32 else 2) < (1 << 20):
+        assert torch.equal(o, o_ref) and torch.equal(q_o, q_ref)
+    else:       # samples of 1 MiB and more: the GroupNorm kernel folds the quad records in gn_qfold_kernel's order, the affine in gn_image_kernel's
+        assert maxrel(o, o_ref) < (1e-5 if dt == L.DC_F32 else 4e-3), maxrel(o, o_ref)
+    idx = smap.long().cpu() if maps else torch.arange(n)
+    hn = q(F.silu(F.group_norm(h.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5))).cpu()[idx]
+    ref = F.conv2d(hn, w, b.cpu(), padding=1) + rv.cpu()[:, :, None, None]
+    if side:
+        ref = ref + torch.einsum("nchw,oc->nohw", xs[idx], ws2)
+    if res:
+        ref = ref + r.float().cpu()[idx].permute(0, 3, 1, 2)
+    assert maxrel(o.float().cpu(), ref.permute(0, 2, 3, 1)) < {L.DC_F32: 3e-5, L.DC_BF16: 1.5e-2, L.DC_F16: 3e-3}[dt]
+
+
 def test_groupnorm_span_kernel_opt_in():
     """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
     test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
