@@ -26,18 +26,31 @@
 static __device__ unsigned long long* g_ws_stamps;
 extern "C" void dc_debug_set_ws_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamps), &p, sizeof(p)); }
 #define DC_STAMP(k) do { if ((threadIdx.x & 255) == 0 && g_ws_stamps) g_ws_stamps[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// cycles spent inside a wait (barrier / vmcnt), summed per team over one tile into slot k: WAIT_T0 before, WAIT_ADD(sum) after
+#define DC_WAIT_T0() const unsigned long long wt0_ = __builtin_amdgcn_s_memtime()
+#define DC_WAIT_ADD(sum) do { sum += __builtin_amdgcn_s_memtime() - wt0_; } while (0)
+#define DC_STAMP_VAL(k, v) do { if ((threadIdx.x & 255) == 0 && g_ws_stamps) g_ws_stamps[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + (k)] = (v); } while (0)
 #else
 #define DC_STAMP(k) do {} while (0)
+#define DC_WAIT_T0() do {} while (0)
+#define DC_WAIT_ADD(sum) do {} while (0)
+#define DC_STAMP_VAL(k, v) do {} while (0)
 #endif
 #include "conv3_halo.h"
 DC_CLOCK_DECL(conv3_ws)
+
+static __device__ chunk16 g_ws_zero_page[4];      // source of the table pieces that have nothing to fetch
 
 struct WsCfg {
   static constexpr int NT = 512, NTL = 256;                 // threads; threads per team
   static constexpr int NXL = 6;                             // LDS-DMA pieces per loader lane per halo chunk (<= 384 halo rows)
   static constexpr int XBUF = NXL * NTL * 16;               // 24 KiB per halo buffer
   static constexpr int WLD = 512 / NTL;                     // W LDS-DMA pieces per loader lane per tap (8 KiB tile)
+#ifdef DC_WS_WR
+  static constexpr int WR = DC_WS_WR;                       // diagnostic builds: deeper W ring (plain variant only: the transform schedule assumes 3)
+#else
   static constexpr int WR = 3;                              // W ring slots (prefetch distance 2 taps)
+#endif
   static constexpr int GNOFF = 2 * XBUF + WR * HALO_WST;    // GroupNorm affine of the workgroup's sample: scale[C], shift[C]
   static constexpr int GNMAXC = 512;
   static constexpr int BRVOFF = GNOFF + 2 * GNMAXC * 4;     // bias + row vector of the N tile (128 floats)
@@ -310,6 +323,399 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
   DC_STAMP(7);
 }
 
+// ====================================================================================================================
+// conv3_wsp_kernel — the same two teams as PERSISTENT workgroups with a software-pipelined MFMA team.
+//
+// What the one-tile kernel above loses (s_memtime stamps, tools/stamp_ws.py): with one workgroup per CU nothing fills (a) the
+// tile's prologue — the loaders' first halo chunk at HBM latency plus its transform, during which the MFMA team idles —, (b) the
+// fragment-read latency and the barrier at the head of every tap (in the 4-wave kernel the SIMD's other wave, from the CU's other
+// workgroup, fills them).  Here:
+//   * a workgroup walks a list of tiles (one workgroup per CU; each XCD label takes a contiguous range of the tile list, its
+//     workgroups stride through it).  Right after a tile's last barrier the loaders fetch, transform and publish the NEXT tile's
+//     first chunk and W tiles while the MFMA team runs the epilogue: the next tile's prologue disappears behind the epilogue.  The
+//     per-tile tables (GroupNorm affine of the sample, bias and row vector of the N tile) arrive by LDS-DMA one tile ahead, into
+//     slots alternating with the tile parity.  W ring slots and halo buffers continue to rotate across tiles.
+//   * the MFMA team's step is { second-half X reads ; 16 MFMAs ; barrier of the NEXT step ; next step's W and first-half X reads ;
+//     16 MFMAs }: every fragment read and the barrier sit under 16 MFMAs of the same wave (W fragments ping-pong between two
+//     register sets by step parity; a chunk has 9 steps, so the chunk body exists for both start parities).
+// Same LDS image, tap order and accumulation order: bit-identical to the one-tile kernel.
+struct WspCfg {
+#ifdef DC_WS_WR
+  static constexpr int WR = DC_WS_WR;
+#else
+  static constexpr int WR = 3;
+#endif
+  static constexpr int NT = 512, NTL = 256, NXL = 6, WLD = 2, TBLN = 2;
+  static constexpr int XBUF = NXL * NTL * 16;
+  static constexpr int GNOFF = 2 * XBUF + WR * HALO_WST;    // [2 tile parities][scale[C] | shift[C]] (4 KiB each)
+  static constexpr int GNMAXC = 512;
+  static constexpr int BRVOFF = GNOFF + 2 * 2 * GNMAXC * 4; // [2 tile parities][bias[128] | rowvec[128]] (1 KiB each)
+  static constexpr int DUMPOFF = BRVOFF + 2 * 256 * 4;      // where placeholder table pieces land (4 + 4 KiB)
+  static constexpr int LDS = DUMPOFF + 8 * 1024;
+};
+
+struct WsLdsBias2 {                                         // bias + row vector of the N tile from their LDS tables (run k: 32 k channels on)
+  static constexpr bool on = true, has_rowvec = true;
+  const float* p;                                           // bias entries; the row vector's sit 128 floats further
+  __device__ __forceinline__ void operator()(int k, float (&bs)[8], float (&)[8]) const {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p + 32 * k), hi = *reinterpret_cast<const f32x4*>(p + 32 * k + 4);
+    const f32x4 rl = *reinterpret_cast<const f32x4*>(p + 128 + 32 * k), rh = *reinterpret_cast<const f32x4*>(p + 128 + 32 * k + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bs[e] = lo[e] + rl[e]; bs[4 + e] = hi[e] + rh[e]; }
+  }
+};
+
+template <typename T, bool GN>
+__global__ __launch_bounds__(512, 2) void conv3_wsp_kernel(const IgemmArgs a, const HaloGeom g, const int total_tiles) {
+  using Cfg = WspCfg;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BKE = 4 * EPC;
+  constexpr int TM = 8, TN = 4, NTAP = 9;
+  constexpr int NTL = Cfg::NTL, NXL = Cfg::NXL, WLD = Cfg::WLD, WR = Cfg::WR, PD = WR - 1, TBLN = Cfg::TBLN;
+  constexpr int FLY = (PD - 1) * WLD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Wring = smem + 2 * Cfg::XBUF;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wave >= 4;
+  const int cw = wave & 3, tl = t & 255;
+  const int tw = 1 << g.ltw, th = 1 << g.lth;
+  const int HW = g.H * g.W;
+  const int Ctot = a.C0 + a.C1;
+  const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
+  const int nx = a.src2 ? a.C2 / BKE : 0;
+  const int tiles_img = g.tiles_x * g.tiles_y;
+  // the workgroup's tiles: XCD label (blockIdx & 7) -> a contiguous range of the tile list, strided over the label's workgroups
+  const int xcd = blockIdx.x & 7, q8 = total_tiles >> 3, r8 = total_tiles & 7;
+  const int lid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+  const int lid_end = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + q8 + (xcd < r8 ? 1 : 0);
+  const int lid_step = ((int)gridDim.x - xcd + 7) >> 3;
+  auto tile_of = [&](int lid, int& tile_m, int& tile_n) __attribute__((always_inline)) {
+    if (a.n_fast) { tile_m = lid / a.tiles_n; tile_n = lid - tile_m * a.tiles_n; }
+    else { tile_n = lid / a.tiles_m; tile_m = lid - tile_n * a.tiles_m; }
+  };
+
+  if (loader) {
+    // =============================================== LOADER TEAM ===============================================
+    const int xlx = tl & 3;
+    const int wrow0 = tl >> 2;
+    const int wvoff = (epi_wrow(wrow0, false) * a.Ktot + ((tl & 3) ^ swz64(wrow0)) * EPC) * (int)sizeof(T);
+    int ldb0 = a.ld0 * (int)sizeof(T), ldb1 = a.ld1 * (int)sizeof(T), ldb2 = a.ld2 * (int)sizeof(T);
+    asm volatile("" : "+s"(ldb0), "+s"(ldb1), "+s"(ldb2));
+    auto rsrc_of = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
+    // per-tile tables by LDS-DMA, TBLN = 2 pieces per lane (absent rows / lanes past the table: offset 0xffffffff -> zeros):
+    //   piece 0: floats [256 cw, 256 cw + 256) of [scale[C] | shift[C]] of the tile's sample;  piece 1 (wave 0): bias | row vector
+    auto issue_tables = [&](int lid, int par, bool real) __attribute__((always_inline)) {
+      // real = false: placeholders (zeros into a dump slot) that only keep the counted waits of every chunk the same
+      int tile_m, tile_n;
+      tile_of(real ? lid : lid0, tile_m, tile_n);
+      const int ng = tile_m / tiles_img;
+      const char* zero = reinterpret_cast<const char*>(g_ws_zero_page);
+      {   // 64-bit per-lane source addresses (the two halves of the table come from two tensors): global_load_lds, not a descriptor
+        const int idx = cw * 256 + 4 * lane;
+        const char* src = zero;
+        if (GN && real && idx < Ctot) src = reinterpret_cast<const char*>(a.gn_scale + (size_t)ng * Ctot + idx);
+        else if (GN && real && idx < 2 * Ctot) src = reinterpret_cast<const char*>(a.gn_shift + (size_t)ng * Ctot + (idx - Ctot));
+        char* dst = real ? smem + Cfg::GNOFF + par * (2 * Cfg::GNMAXC * 4) + cw * 1024 : smem + Cfg::DUMPOFF + cw * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      }
+      {   // wave 0: bias | row vector of the N tile; the other waves' piece is always a placeholder
+        const int c = tile_n * 128 + 4 * (lane & 31);
+        const int rrow = (real && a.rowvec) ? __builtin_amdgcn_readfirstlane(a.rowvec_map ? a.rowvec_map[ng] : ng) : 0;
+        const char* src = zero;
+        if (real && cw == 0 && c < a.Cout) {
+          if (lane < 32) { if (a.bias) src = reinterpret_cast<const char*>(a.bias + c); }
+          else if (a.rowvec) src = reinterpret_cast<const char*>(a.rowvec + (size_t)rrow * a.rowvec_ld + c);
+        }
+        char* dst = (real && cw == 0) ? smem + Cfg::BRVOFF + par * 1024 : smem + Cfg::DUMPOFF + 4096 + cw * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      }
+    };
+    // first tile's tables: fetched, landed and published before anything reads them (the one extra barrier of the kernel)
+    issue_tables(lid0, 0, lid0 < lid_end);
+    hwait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int sb = 0, xpar = 0, tc = 0;                    // W ring phase, halo buffer parity, tile counter (all continue across tiles)
+    for (int lid = lid0; lid < lid_end; lid += lid_step, ++tc) {
+      int tile_m, tile_n;
+      tile_of(lid, tile_m, tile_n);
+      const int tx = tile_m % g.tiles_x, ty = (tile_m / g.tiles_x) % g.tiles_y, ng = tile_m / tiles_img;
+      const int par = tc & 1;
+      const float* gnp = reinterpret_cast<const float*>(smem + Cfg::GNOFF + par * (2 * Cfg::GNMAXC * 4));
+      int pp[NXL];
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) {
+        const int hr = (i * NTL + tl) >> 2;
+        pp[i] = -1;
+        if (i < g.nxl && hr < g.HR) {
+          const int hy = (int)(((float)hr + 0.5f) * g.inv_hw), hx = hr - hy * g.hw;
+          const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
+          if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) pp[i] = iy * g.W + ix;
+        }
+      }
+      const int s0 = __builtin_amdgcn_readfirstlane(a.map0 ? a.map0[ng] : ng);
+      const T* xb0 = reinterpret_cast<const T*>(a.src0) + (size_t)s0 * HW * a.ld0;
+      const T* xb1 = nullptr; const T* xb2 = nullptr;
+      if (a.src1) { const int s1 = __builtin_amdgcn_readfirstlane(a.map1 ? a.map1[ng] : ng); xb1 = reinterpret_cast<const T*>(a.src1) + (size_t)s1 * HW * a.ld1; }
+      if (a.src2) { const int s2 = __builtin_amdgcn_readfirstlane(a.map2 ? a.map2[ng] : ng); xb2 = reinterpret_cast<const T*>(a.src2) + (size_t)s2 * HW * a.ld2; }
+      const int wtile0 = tile_n * 128 * a.Ktot;
+
+      auto issue_x = [&](int cc) __attribute__((always_inline)) {                // cc >= nchunks: chunk cc - nchunks of the 1x1 side source
+        int ldb = ldb0, cb = cc;
+        const T* xb = xb0;
+        if (cc >= nchunks) { ldb = ldb2; cb = cc - nchunks; xb = xb2; }
+        else if (cc >= c0chunks) { ldb = ldb1; cb = cc - c0chunks; xb = xb1; }
+        const int cofs = cb * 64 + xlx * 16;
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(xb);
+        char* xs = smem + ((xpar + cc) & 1) * Cfg::XBUF + cw * 1024;
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+          const int pk = pp[i];
+          const int voff = pk < 0 ? -1 : pk * ldb + cofs;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(xs + i * (NTL * 16)), 16, voff, 0, 0, 0);
+        }
+      };
+      auto issue_w = [&](int cc, int tap, int slot) __attribute__((always_inline)) {
+        const int so = (wtile0 + tap * Ctot + cc * BKE) * (int)sizeof(T);
+        const __amdgpu_buffer_rsrc_t wrs = rsrc_of(a.W);
+#pragma unroll
+        for (int i = 0; i < WLD; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(Wring + slot * HALO_WST + i * (NTL * 16) + cw * 1024), 16, wvoff,
+                                                   so + i * 64 * a.Ktot * (int)sizeof(T), 0, 0);
+      };
+      auto issue_w2 = [&](int e, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+          const int row = (i * NTL + tl) >> 2;
+          const T* wp = reinterpret_cast<const T*>(a.W2) + (size_t)(tile_n * 128 + epi_wrow(row, false)) * a.C2 + ((tl & 3) ^ swz64(row)) * EPC + e * BKE;
+          __builtin_amdgcn_global_load_lds((gptr_t) reinterpret_cast<const char*>(wp),
+                                           (lptr_t)(Wring + slot * HALO_WST + i * (NTL * 16) + cw * 1024), 16, 0, 0);
+        }
+      };
+      float scr[EPC], shr[EPC];
+      auto load_affine = [&](int ccx) __attribute__((always_inline)) {
+        const float* sc = gnp + ccx * BKE + xlx * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { scr[e] = sc[e]; shr[e] = sc[Ctot + e]; }
+      };
+      auto xform = [&](int ccx, int i) __attribute__((always_inline)) {
+        if (pp[i] >= 0) {
+          chunk16* q = reinterpret_cast<chunk16*>(smem + ((xpar + ccx) & 1) * Cfg::XBUF + (i * NTL + tl) * 16);
+          float f[EPC];
+          chunk_to_f<T>(*q, f);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float v = f[e] * scr[e] + shr[e];
+            if (a.gn_silu) v = silu_t<T>(v);
+            f[e] = v;
+          }
+          *q = f_to_chunk<T>(f);
+        }
+      };
+
+      [[maybe_unused]] unsigned long long lvm = 0, lbar = 0;   // diagnostic builds: cycles in the counted vmcnt waits / at the barriers
+      if (tc == 1) DC_STAMP(1);
+      // the tile's first chunk and W tiles: issued right after the PREVIOUS tile's last barrier — that tile's last step reads the
+      // other halo buffer and ring slot (sb + 2) % 3 = the slot before sb; slots sb, sb + 1 and this buffer were released earlier
+      issue_x(0);
+#pragma unroll
+      for (int i = 0; i < PD; ++i) issue_w(0, i, (sb + i) % WR);
+      if (GN) {
+        hwait_vmcnt<PD * WLD>();
+        load_affine(0);
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) xform(0, i);
+      }
+      for (int cc = 0; cc < nchunks; ++cc) {
+        const bool side_next = cc + 1 == nchunks && nx > 0;
+        const bool has_next = cc + 1 < nchunks || side_next;
+        const bool gn_next = GN && cc + 1 < nchunks;
+        const int s0c = cc * NTAP;
+        auto step = [&](auto tapc) __attribute__((always_inline)) {
+          constexpr int tap = decltype(tapc)::value;
+          // as in the one-tile kernel, plus the TBLN table pieces issued at tap 0 behind X(cc+1)
+          {
+            DC_WAIT_T0();
+            if (has_next) {
+              if (tap >= 1 && tap <= PD) hwait_vmcnt<FLY + NXL + TBLN>();
+              else hwait_vmcnt<FLY>();
+            } else {
+              constexpr int left = NTAP - 1 - tap;
+              hwait_vmcnt<(left < PD - 1 ? left : PD - 1) * WLD + ((tap >= 1 && tap <= PD) ? TBLN : 0)>();
+            }
+            if (GN && tap == 0) __builtin_amdgcn_s_waitcnt(0xC07F);
+            DC_WAIT_ADD(lvm);
+          }
+          {
+            DC_WAIT_T0();
+            __builtin_amdgcn_s_barrier();
+            DC_WAIT_ADD(lbar);
+          }
+          constexpr int t2 = tap + PD;                     // the ring slot of the tile's step s is (sb + s) % WR
+          if (t2 < NTAP) issue_w(cc, t2, (sb + s0c + t2) % WR);
+          else if (side_next) { if (t2 - NTAP < nx) issue_w2(t2 - NTAP, (sb + s0c + t2) % WR); }
+          else if (has_next) issue_w(cc + 1, t2 - NTAP, (sb + s0c + t2) % WR);
+          if (tap == 0 && has_next) issue_x(cc + 1);
+          if (tap == 0) issue_tables(lid + lid_step, par ^ 1, cc == 0 && lid + lid_step < lid_end);   // chunk 0: the next tile's tables; else placeholders
+          if (tap == PD + 1 && gn_next) load_affine(cc + 1);
+          if (tap > PD && gn_next) xform(cc + 1, tap > PD ? tap - PD - 1 : 0);
+        };
+        step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
+      }
+      for (int e = 0; e < nx; ++e) {
+        if (e == 0 && nx >= PD) hwait_vmcnt<FLY>();
+        else hwait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (e + PD < nx) issue_w2(e + PD, (sb + nchunks * NTAP + e + PD) % WR);
+        if (e + 1 < nx) issue_x(nchunks + e + 1);
+      }
+      if (tc == 1) { DC_STAMP(2); DC_STAMP_VAL(3, lbar); DC_STAMP_VAL(4, lvm); }
+      sb = (sb + nchunks * NTAP + nx) % WR;         // (WR = 3: the nchunks * 9 steps leave the ring phase where it was)
+      xpar = (xpar + nchunks + nx) & 1;
+    }
+    return;
+  }
+
+  // ================================================= MFMA TEAM =================================================
+  const int wm = cw >> 1, wn = cw & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int xl = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64 + lq * 16;
+  int joff[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int p = wm * 128 + j * 16;
+    const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
+    joff[j] = __builtin_amdgcn_readfirstlane((py * g.hw + px) * 64);
+  }
+  const int woff0 = lds64_off(wn * 64 + lr, lq);
+  __builtin_amdgcn_s_barrier();                      // the first tile's tables are in
+
+  int sb = 0, xpar = 0, tc = 0;
+  for (int lid = lid0; lid < lid_end; lid += lid_step, ++tc) {
+    int tile_m, tile_n;
+    tile_of(lid, tile_m, tile_n);
+    const int tx = tile_m % g.tiles_x, ty = (tile_m / g.tiles_x) % g.tiles_y, ng = tile_m / tiles_img;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // One step = 32 MFMAs in four quarters of 8: (W01 x XA) (W01 x XB) (W23 x XA) (W23 x XB) — W01 / W23 = cout fragments 0-1 / 2-3,
+    // XA / XB = pixel fragments 0-3 / 4-7.  A register set is re-loaded for the NEXT step as soon as its last quarter has been
+    // issued: W01 after the second quarter (behind the next step's barrier), XA after the third, XB and W23 after the fourth; every
+    // read then has at least 8 MFMAs (128 matrix cycles) between its issue and its first use, with ONE register set per operand
+    // (no ping-pong, no step parity).  Each accumulator still takes exactly one product per step, in step order: same sums.
+    chunk16 w01[2], w23[2], xa[TM / 2], xb[TM / 2];
+    [[maybe_unused]] unsigned long long wbar = 0;      // diagnostic builds: cycles this wave waited at the steps' barriers
+    // (the per-lane address parts enter every read through an opaque copy: hoisted out of the tap / chunk / tile loops the
+    //  fragment addresses of a chunk would live in registers next to the accumulators, and spill)
+    auto rd_w01 = [&](const char* Wst) __attribute__((always_inline)) {
+      int wo = woff0;
+      asm volatile("" : "+v"(wo));
+      w01[0] = *reinterpret_cast<const chunk16*>(Wst + wo);
+      w01[1] = *reinterpret_cast<const chunk16*>(Wst + wo + 1024);
+    };
+    auto rd_w23 = [&](const char* Wst) __attribute__((always_inline)) {
+      int wo = woff0;
+      asm volatile("" : "+v"(wo));
+      w23[0] = *reinterpret_cast<const chunk16*>(Wst + wo + 2048);
+      w23[1] = *reinterpret_cast<const chunk16*>(Wst + wo + 3072);
+    };
+    auto rd_xa = [&](const char* Xb, int tapoff) __attribute__((always_inline)) {
+      int xo = xl;
+      asm volatile("" : "+v"(xo));
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j) xa[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[j]) + xo);
+    };
+    auto rd_xb = [&](const char* Xb, int tapoff) __attribute__((always_inline)) {
+      int xo = xl;
+      asm volatile("" : "+v"(xo));
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j) xb[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[TM / 2 + j]) + xo);
+    };
+    // `more`: another step follows (its W tile at Wn, its halo buffer Xn, tap offset tapoff_n)
+    auto step = [&](bool more, const char* Wn, const char* Xn, int tapoff_n) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j) { acc[0][j] = Mma<T>::run(w01[0], xa[j], acc[0][j]); acc[1][j] = Mma<T>::run(w01[1], xa[j], acc[1][j]); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j) { acc[0][TM / 2 + j] = Mma<T>::run(w01[0], xb[j], acc[0][TM / 2 + j]); acc[1][TM / 2 + j] = Mma<T>::run(w01[1], xb[j], acc[1][TM / 2 + j]); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        // every read of this step is back (the last, W23, was issued a step ago) before the next step's barrier lets the loaders
+        // refill what it read
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w23[0]), "+v"(w23[1]));
+        {
+          DC_WAIT_T0();
+          __builtin_amdgcn_s_barrier();
+          DC_WAIT_ADD(wbar);
+        }
+        rd_w01(Wn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j) { acc[2][j] = Mma<T>::run(w23[0], xa[j], acc[2][j]); acc[3][j] = Mma<T>::run(w23[1], xa[j], acc[3][j]); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) rd_xa(Xn, tapoff_n);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TM / 2; ++j) { acc[2][TM / 2 + j] = Mma<T>::run(w23[0], xb[j], acc[2][TM / 2 + j]); acc[3][TM / 2 + j] = Mma<T>::run(w23[1], xb[j], acc[3][TM / 2 + j]); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) { rd_xb(Xn, tapoff_n); rd_w23(Wn); }
+    };
+    const int S = nchunks * NTAP + nx;               // steps of the tile
+    const int hw64 = g.hw * 64;
+    auto slot_of = [&](int s) __attribute__((always_inline)) { return Wring + ((sb + s) % WR) * HALO_WST; };
+    auto xbuf_of = [&](int c) __attribute__((always_inline)) { return smem + ((xpar + c) & 1) * Cfg::XBUF; };
+    // step 0's operands
+    if (tc == 1) DC_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    rd_w01(slot_of(0)); rd_xa(xbuf_of(0), 0); rd_xb(xbuf_of(0), 0); rd_w23(slot_of(0));
+    for (int cc = 0; cc < nchunks; ++cc) {
+      const char* Xb = xbuf_of(cc);
+      const int s0c = cc * NTAP;
+      auto tap = [&](auto tapc) __attribute__((always_inline)) {
+        constexpr int tp = decltype(tapc)::value;
+        if constexpr (tp < NTAP - 1) {
+          constexpr int kyn = (tp + 1) / 3, kxn = (tp + 1) - kyn * 3;
+          step(true, slot_of(s0c + tp + 1), Xb, kyn * hw64 + kxn * 64);
+        } else {
+          // tap 8: the next step is tap 0 of the next chunk, or the first side step (centre tap), or nothing
+          step(s0c + NTAP < S, slot_of(s0c + NTAP), xbuf_of(cc + 1), cc + 1 < nchunks ? 0 : hw64 + 64);
+        }
+      };
+      tap(IC<0>{}); tap(IC<1>{}); tap(IC<2>{}); tap(IC<3>{}); tap(IC<4>{}); tap(IC<5>{}); tap(IC<6>{}); tap(IC<7>{}); tap(IC<8>{});
+    }
+    for (int e = 0; e < nx; ++e)                     // 1x1 side source: centre tap of chunk nchunks + e
+      step(e + 1 < nx, slot_of(nchunks * NTAP + e + 1), xbuf_of(nchunks + e + 1), hw64 + 64);
+    if (tc == 1) { DC_STAMP(2); DC_STAMP_VAL(3, wbar); }
+    sb = (sb + nchunks * NTAP + nx) % WR;
+    xpar = (xpar + nchunks + nx) & 1;
+    // ---- epilogue: straight from the accumulators; bias / row vector from this tile's LDS tables ----
+    HaloQs qsfn;
+    qsfn.nbase = ng; qsfn.ltp = g.ltw + g.lth; qsfn.n_img = g.n_img; qsfn.tile_in_img = ty * g.tiles_x + tx; qsfn.wm = wm;
+    qsfn.np = HW >= 128 ? HW >> 7 : 1;
+    qsfn.padd = 0;
+    auto rowfn = [&](int j, EpiRow& r) __attribute__((always_inline)) {
+      const int p = wm * 128 + j * 16 + lr;
+      const int py = (p >> g.ltw) & (th - 1), px = p & (tw - 1);
+      const int rem = (ty * th + py) * g.W + tx * tw + px;
+      r.ok = true;
+      r.samp = ng;
+      r.o = ng * HW + rem;
+      r.r = (a.residual && a.res_map ? a.res_map[ng] : ng) * HW + rem;
+    };
+    const float* brv = reinterpret_cast<const float*>(smem + Cfg::BRVOFF + (tc & 1) * 1024);
+    epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, ng, ng, rowfn, EpiNoPre(), qsfn, WsLdsBias2{brv + wn * 64 + lq * 8});
+    if (tc == 1) DC_STAMP(7);
+    if (tc == 0) DC_STAMP(0);        // (diagnostic builds: the workgroup's SECOND tile is the stamped one — steady state)
+  }
+}
+
 static int ws_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // true when the wave-specialised kernel can take this problem: what conv3_halo's one-image-per-patch / buffer-descriptor form takes
@@ -355,9 +761,36 @@ static int launch_ws(const IgemmArgs& a0, int n_img, hipStream_t s) {
   a.tiles_m = n_img * g.tiles_x * g.tiles_y;
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_ws: bad grid %lld", nblk); return DC_ERR_SHAPE; }
-  void (*kern)(const IgemmArgs, const HaloGeom) = a.gn_scale ? conv3_ws_kernel<T, true> : conv3_ws_kernel<T, false>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
-  return dc_check_launch("dc_igemm(conv3_ws)");
+  // The persistent form (conv3_wsp_kernel) is OPT-IN (DCAMD_WS_PERSIST): measured on cfg2 it is 5 % slower than the one-tile kernel
+  // (28.6 vs 27.0 ms per step over the 20 fused convs).  s_memtime accounting (tools/stamp_ws.py, profiles/r03_stamp_ws_*.log): the
+  // LOADER team is the pole — ~200 cycles of its own time per LDS-DMA piece (104 pieces per tile: the CU's LDS-DMA issue path at
+  // ~20-25 B/clk), plus ~490 per transformed piece, all between lock-step barriers — so the pipelined MFMA team still waits at every
+  // step's barrier (loop 34-38 k cycles against 18.4 k of MFMA issue), and with the next tile's DMA running under it the epilogue
+  // takes 23 k cycles instead of 14.6 k.  See DESIGN.md 8.
+  static const bool one_tile = getenv("DCAMD_WS_PERSIST") == nullptr;
+  if (one_tile) {
+    void (*kern)(const IgemmArgs, const HaloGeom) = a.gn_scale ? conv3_ws_kernel<T, true> : conv3_ws_kernel<T, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
+    return dc_check_launch("dc_igemm(conv3_ws)");
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dc_set_error("conv3_ws: no device properties"); return DC_ERR_LAUNCH; }
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  static bool attr_p = false;
+  if (!attr_p) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wsp_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WspCfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wsp_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, WspCfg::LDS);
+    attr_p = true;
+  }
+  // one workgroup per CU (8 waves at <= 256 registers, 83 KiB of LDS); every XCD label needs at least one workgroup per 8 tiles
+  const int grid = (int)(nblk < n_cu ? nblk : n_cu);
+  void (*kp)(const IgemmArgs, const HaloGeom, const int) = a.gn_scale ? conv3_wsp_kernel<T, true> : conv3_wsp_kernel<T, false>;
+  hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(WspCfg::NT), WspCfg::LDS, s, a, g, (int)nblk);
+  return dc_check_launch("dc_igemm(conv3_wsp)");
 }
 
 int dc_conv3_ws_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s) {

@@ -6,10 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "libdcamd_stamps.so")
 src = os.path.join(ROOT, "diffusion-classifier_amd", "csrc")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDC_STAMPS", "-shared",
-                f"-I{ROOT}/include", "-o", out] + [os.path.join(src, f) for f in
-                ("igemm.hip", "igemm_pipe.hip", "igemm_xreg.hip", "conv3_halo.hip", "norms.hip", "attention.hip", "attention_mfma.hip", "elementwise.hip", "stage.hip", "pack.hip", "api.hip")], check=True)
+srcs = [f for f in sorted(os.listdir(src)) if f.endswith(".hip")]
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDC_STAMPS", "-shared", "-Wno-unused-function",
+                f"-I{ROOT}/include", "-o", out] + [os.path.join(src, f) for f in srcs], check=True)
 os.environ["DCAMD_LIB"] = out
+os.environ["DCAMD_NO_WS"] = "1"        # this tool stamps conv3_halo_kernel (tools/stamp_ws.py: the wave-specialised kernel)
 import torch
 import diffusion_classifier_amd as dca
 from diffusion_classifier_amd import _lib as L, engine as E
