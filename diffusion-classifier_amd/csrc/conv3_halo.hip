@@ -66,7 +66,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int wm = wave >> 1, wn = wave & 1;      // NW/2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
-  tile_of_block(a, tile_m, tile_n);
+  if constexpr (XB) tile_of_block_scalar(a, tile_m, tile_n);     // buffer-descriptor loaders: scalar offsets must be SGPRs (no waterfall loops)
+  else tile_of_block(a, tile_m, tile_n);
   constexpr bool UP4 = NTAP == 4;
   int phase = 0;
   if (UP4) { const int tn = a.tiles_n >> 2; phase = tile_n / tn; tile_n -= phase * tn; }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 #pragma unroll
       for (int i = 0; i < WLD; ++i)    // piece i: LDS rows 64 i + (t >> 2) = packed rows 64 further (epi_wrow and the swizzle keep the low part)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(Wring + slot * HALO_WST + i * (NT * 16) + wave * 1024), 16, wvoff,
-                                                 so + i * 64 * a.Ktot * (int)sizeof(T), 0, 0);
+                                                 __builtin_amdgcn_readfirstlane(so + i * 64 * a.Ktot * (int)sizeof(T)), 0, 0);
     } else {
       const T* wb = reinterpret_cast<const T*>(a.W) + (size_t)wtile0 + (size_t)tap * Ctot + (size_t)cc * BKE;   // wave-uniform
       int tt = t;

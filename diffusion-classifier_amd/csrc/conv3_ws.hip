@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
   const bool loader = wave >= 4;                // wave-uniform (scalar branch)
   const int cw = wave & 3, tl = t & 255;        // wave / thread inside the team
   int tile_m, tile_n;
-  tile_of_block(a, tile_m, tile_n);
+  tile_of_block_scalar(a, tile_m, tile_n);
   const int tx = tile_m % g.tiles_x;
   const int ty = (tile_m / g.tiles_x) % g.tiles_y;
   const int ng = tile_m / (g.tiles_x * g.tiles_y);      // one image per patch: the workgroup's sample
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
 #pragma unroll
       for (int i = 0; i < WLD; ++i)             // piece i: LDS rows 64 i + (tl >> 2) = packed rows 64 further
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(Wring + slot * HALO_WST + i * (NTL * 16) + cw * 1024), 16, wvoff,
-                                                 so + i * 64 * a.Ktot * (int)sizeof(T), 0, 0);
+                                                 __builtin_amdgcn_readfirstlane(so + i * 64 * a.Ktot * (int)sizeof(T)), 0, 0);
     };
     auto issue_w2 = [&](int e, int slot) {      // side source weights W2 [Cout_pad][C2]: chunk e, same LDS tile image
 #pragma unroll
@@ -395,6 +395,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wsp_kernel(const IgemmArgs a, co
   auto tile_of = [&](int lid, int& tile_m, int& tile_n) __attribute__((always_inline)) {
     if (a.n_fast) { tile_m = lid / a.tiles_n; tile_n = lid - tile_m * a.tiles_n; }
     else { tile_n = lid / a.tiles_m; tile_m = lid - tile_n * a.tiles_m; }
+    tile_m = __builtin_amdgcn_readfirstlane(tile_m);     // (the divisions run on the vector unit: see tile_of_block_scalar)
+    tile_n = __builtin_amdgcn_readfirstlane(tile_n);
   };
 
   if (loader) {
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wsp_kernel(const IgemmArgs a, co
 #pragma unroll
         for (int i = 0; i < WLD; ++i)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(Wring + slot * HALO_WST + i * (NTL * 16) + cw * 1024), 16, wvoff,
-                                                   so + i * 64 * a.Ktot * (int)sizeof(T), 0, 0);
+                                                   __builtin_amdgcn_readfirstlane(so + i * 64 * a.Ktot * (int)sizeof(T)), 0, 0);
       };
       auto issue_w2 = [&](int e, int slot) __attribute__((always_inline)) {
 #pragma unroll

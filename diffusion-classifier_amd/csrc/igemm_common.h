@@ -144,6 +144,19 @@ int dc_igemm_pipe_shape(const IgemmArgs& a);   // 0: 128x128, 1: 256x128, 2: 256
 // igemm_wide.hip: the 256 x 256 tile on the 8-phase main loop (DCAMD_WIDE_OLD keeps the 2-stage loop of igemm_pipe.hip: A/B runs)
 int dc_igemm_launch_wide8(const IgemmArgs& a, int dtype, hipStream_t s);
 bool dc_igemm_wide8_enabled();
+// hipcc expands the integer divisions of tile_of_block on the VECTOR unit, so tile_m / tile_n (and everything derived from them: weight
+// panel offsets, sample indices, descriptor bases) live in VGPRs although they are wave-uniform — and every `buffer_load ... lds` that
+// takes such a value as its SCALAR offset is wrapped in a waterfall loop (v_readfirstlane / v_cmp / s_and_saveexec / branch: ~10
+// instructions and a serialising round trip per LDS-DMA piece: 40 of the 70 LDS-DMA instructions of conv3_halo's one-image-per-patch
+// form were; cdna_hip_programming.md T20).  One readfirstlane each makes the whole chain scalar.  Only for the kernels that feed
+// buffer descriptors: the per-lane-address forms sit at the register limit and spill (48-269 VGPRs) when their scalar count changes.
+__device__ __forceinline__ void tile_of_block_scalar(const IgemmArgs& a, int& tile_m, int& tile_n) {
+  tile_of_block(a, tile_m, tile_n);
+  tile_m = __builtin_amdgcn_readfirstlane(tile_m);
+  tile_n = __builtin_amdgcn_readfirstlane(tile_n);
+  asm volatile("" : "+s"(tile_m), "+s"(tile_n));      // pin them in SGPRs (a bare readfirstlane of a uniform value may be folded away)
+}
+
 // conv3_halo.hip
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype);
 bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype);   // fused GroupNorm prologue possible

@@ -23,6 +23,13 @@ def family(kernel):
         if len(ints) > 1 and ints[1] == 4:                      # NTAP = 4: the four-phase upsample conv
             return f"conv3_up4<{dt},{ints[0]}w>"
         return f"conv3_halo<{dt},{ints[0]}w>"
+    if "conv3_ws_kernel" in k or "conv3_wsp_kernel" in k:      # <T, GN>: wave-specialised halo conv (the persistent form is the same family)
+        gn = "Lb1E" in k or "true" in k
+        if "_Accum" in k:          # rocprofv3's demangler garbles <__bf16, bool>: the bench runs it in bf16 only
+            dt, gn = "bf16", True
+        return f"conv3_ws<{dt},gn>" if gn else f"conv3_ws<{dt}>"
+    if "igemm_wide8_kernel" in k:
+        return f"igemm_wide8<{dt},256x256>"
     if "conv3_thin_kernel" in k:
         if "_Accum" in k:          # rocprofv3's demangler garbles <__bf16, bool> into "<bool _Accum, bool, E>": the bench runs it in bf16 only
             dt = "bf16"
