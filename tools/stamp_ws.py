@@ -16,6 +16,8 @@ if not gn:
     os.environ["DCAMD_WS_PLAIN"] = "1"
 if os.environ.get("ONE_TILE"):
     os.environ["DCAMD_WS_ONE_TILE"] = "1"
+if os.environ.get("PERSIST"):
+    os.environ["DCAMD_WS_PERSIST"] = "1"
 import torch
 from diffusion_classifier_amd import _lib as L, engine as E
 lib = L.lib()
@@ -46,7 +48,7 @@ s = st.view(nblk, 2, 8).cpu().double()
 for team, nm in ((0, "MFMA team"), (1, "loader team"))[: 2 if os.environ.get("ONE_TILE") else 1]:
     t = s[:, team]
     print(f"{nm}: setup {(t[:,1]-t[:,0]).median():.0f}  main loop {(t[:,2]-t[:,1]).median():.0f}" + (f"  epilogue {(t[:,7]-t[:,2]).median():.0f}  total {(t[:,7]-t[:,0]).median():.0f}" if team == 0 else f"  total {(t[:,2]-t[:,0]).median():.0f}"))
-if not os.environ.get("ONE_TILE"):
+if os.environ.get("PERSIST"):
     m, l = s[:, 0], s[:, 1]
     print(f"MFMA team (second tile): loop {(m[:,2]-m[:,1]).median():.0f} cycles, of which at barriers {m[:,3].median():.0f}")
     print(f"loader team (second tile): loop {(l[:,2]-l[:,1]).median():.0f} cycles, of which at barriers {l[:,3].median():.0f}, in counted vmcnt waits {l[:,4].median():.0f}")
