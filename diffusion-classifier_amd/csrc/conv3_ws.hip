@@ -30,7 +30,15 @@ extern "C" void dc_debug_set_ws_stamps(unsigned long long* p) { (void)hipMemcpyT
 #define DC_WAIT_T0() const unsigned long long wt0_ = __builtin_amdgcn_s_memtime()
 #define DC_WAIT_ADD(sum) do { sum += __builtin_amdgcn_s_memtime() - wt0_; } while (0)
 #define DC_STAMP_VAL(k, v) do { if ((threadIdx.x & 255) == 0 && g_ws_stamps) g_ws_stamps[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + (k)] = (v); } while (0)
+// timing-only ablations of the one-tile kernel (results are wrong on purpose): 1 no MFMAs, 2 W LDS-DMA through a zero-record
+// descriptor (the range check drops the fetch, the instruction stays), 4 the same for the halo chunks, 8 no transform, 16 no LDS-DMA
+// instructions at all, 32 no fragment reads (and no MFMAs); conv3_wr_kernel: 8, and 64 = W fragment loads shaped as a fragment-major
+// weight image would make them (1 KiB contiguous per instruction)
+static __device__ int g_ws_abl;
+extern "C" void dc_debug_set_ws_abl(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ws_abl), &v, sizeof(v)); }
+#define DC_WS_ABL() __builtin_amdgcn_readfirstlane(g_ws_abl)
 #else
+#define DC_WS_ABL() 0
 #define DC_STAMP(k) do {} while (0)
 #define DC_WAIT_T0() do {} while (0)
 #define DC_WAIT_ADD(sum) do {} while (0)
@@ -71,6 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
   float* const brv = reinterpret_cast<float*>(smem + Cfg::BRVOFF);
 
   DC_STAMP(0);
+  const int abl = DC_WS_ABL();                  // 0 outside diagnostic builds
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     const int wrow0 = tl >> 2;                  // LDS row of the lane's first W piece (piece i is 64 rows further)
     const int wvoff = (epi_wrow(wrow0, false) * a.Ktot + ((tl & 3) ^ swz64(wrow0)) * EPC) * (int)sizeof(T);
     const int wtile0 = tile_n * 128 * a.Ktot;   // element offset of the N tile; < 2^30 (host check)
-    auto rsrc_of = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
+    auto rsrc_of = [](const void* base, int rec = 0x7fffffff) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, rec, 0x00020000); };
 
     auto issue_x = [&](int cc) {                // cc >= nchunks: chunk cc - nchunks of the 1x1 side source
       int ldb = ldb0, cb = cc;
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
       if (cc >= nchunks) { ldb = ldb2; cb = cc - nchunks; xb = xb2; }
       else if (cc >= c0chunks) { ldb = ldb1; cb = cc - c0chunks; xb = xb1; }
       const int cofs = cb * 64 + xlx * 16;
-      const __amdgpu_buffer_rsrc_t rs = rsrc_of(xb);
+      const __amdgpu_buffer_rsrc_t rs = rsrc_of(xb, (abl & 4) ? 0 : 0x7fffffff);
+      if (abl & 16) return;
       char* xs = smem + (cc & 1) * Cfg::XBUF + cw * 1024;
 #pragma unroll
       for (int i = 0; i < NXL; ++i) {
@@ -153,7 +163,8 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     };
     auto issue_w = [&](int cc, int tap, int slot) {
       const int so = (wtile0 + tap * Ctot + cc * BKE) * (int)sizeof(T);         // wave-uniform: scalar offset
-      const __amdgpu_buffer_rsrc_t wrs = rsrc_of(a.W);
+      const __amdgpu_buffer_rsrc_t wrs = rsrc_of(a.W, (abl & 2) ? 0 : 0x7fffffff);
+      if (abl & 16) return;
 #pragma unroll
       for (int i = 0; i < WLD; ++i)             // piece i: LDS rows 64 i + (tl >> 2) = packed rows 64 further
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(Wring + slot * HALO_WST + i * (NTL * 16) + cw * 1024), 16, wvoff,
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
       for (int e = 0; e < EPC; ++e) { scr[e] = sc[e]; shr[e] = sc[Ctot + e]; }
     };
     auto xform = [&](int ccx, int i) {
-      if (pp[i] >= 0) {
+      if (pp[i] >= 0 && !(abl & 8)) {
         chunk16* q = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (i * NTL + tl) * 16);
         float f[EPC];
         chunk_to_f<T>(*q, f);
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // one tap of one channel chunk: W fragments, then the X fragments in two halves; MFMAs in j-major order (the 4-wave kernel's order)
   auto mma_tap = [&](const char* Wst, const char* Xb, int tapoff) {
+    if (abl & 32) return;
     chunk16 wf[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff0 + i * 1024);
@@ -275,6 +287,15 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
       chunk16 xf[TM / 2];
 #pragma unroll
       for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[h * (TM / 2) + j]) + xl);
+#ifdef DC_STAMPS
+      if (abl & 1) {                              // timing only: the fragments are read, nothing is multiplied
+#pragma unroll
+        for (int j = 0; j < TM / 2; ++j) asm volatile("" ::"v"(xf[j]));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(wf[i]));
+        continue;
+      }
+#endif
 #pragma unroll
       for (int j = 0; j < TM / 2; ++j)
 #pragma unroll
@@ -767,6 +788,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wr_kernel(const IgemmArgs a, con
   const int c0chunks = a.C0 / BKE, nchunks = Ctot / BKE;
   const int nx = a.src2 ? a.C2 / BKE : 0;
   const int NC = nchunks + nx;                              // chunks per tile (the side source's are single-step chunks)
+  const int abl = DC_WS_ABL();
   const int tiles_img = g.tiles_x * g.tiles_y;
   const int xcd = blockIdx.x & 7, q8 = total_tiles >> 3, r8 = total_tiles & 7;
   const int lid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
@@ -881,7 +903,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wr_kernel(const IgemmArgs a, con
         const bool prev_tile = (k < N) ? ci == 0 : true;
         const int ct = (k < N && ci > 0) ? ci - 1 : NC - 1;
         const int tpar = (k < N) ? ((prev_tile ? ti - 1 : ti) & 1) : ((ntile - 1) & 1);
-        if (GN && ct < nchunks) {
+        if (GN && ct < nchunks && !(abl & 8)) {
           const float* gnp = reinterpret_cast<const float*>(smem + Cfg::GNOFF + tpar * (2 * Cfg::GNMAXC * 4));
           const float* sc = gnp + ct * BKE + xlx * EPC;
           float scr[EPC], shr[EPC];
@@ -950,6 +972,13 @@ __global__ __launch_bounds__(512, 2) void conv3_wr_kernel(const IgemmArgs a, con
     // W fragments of step (chunk cc, tap tp) of the 3x3 part / of side step e, into set P
     auto ld_w = [&](auto pc, int cc, int tp) __attribute__((always_inline)) {
       constexpr int P = decltype(pc)::value;
+#ifdef DC_WR_CONTIG     // timing only (diagnostic builds): the fragment loads a fragment-major weight image would need (1 KiB contiguous each)
+      const int soc = __builtin_amdgcn_readfirstlane(wt0 + ((cc * NTAP + tp) * 8 + wn * 4) * 1024);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        ws[P][i] = __builtin_bit_cast(chunk16, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, soc + i * 1024, 0));
+      return;
+#endif
       const int so = __builtin_amdgcn_readfirstlane(wt0 + (tp * Ctot + cc * BKE) * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < TN; ++i)
