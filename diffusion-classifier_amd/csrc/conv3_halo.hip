@@ -30,8 +30,14 @@
 static __device__ unsigned long long* g_stamps;
 extern "C" void dc_debug_set_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
 #define DC_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// timing-only ablations of the staggered loop (results wrong on purpose): 1 no MFMAs, 2 no fragment reads, 4 no LDS-DMA instructions,
+// 8 no halo LDS-DMA instructions (the W tiles are still fetched)
+static __device__ int g_halo_abl;
+extern "C" void dc_debug_set_halo_abl(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_halo_abl), &v, sizeof(v)); }
+#define DC_HALO_ABL() __builtin_amdgcn_readfirstlane(g_halo_abl)
 #else
 #define DC_STAMP(k) do {} while (0)
+#define DC_HALO_ABL() 0
 #endif
 #include "igemm_epilogue.h"
 
@@ -48,8 +54,23 @@ DC_CLOCK_DECL(conv3_halo)
 // patch); 2 (MOS) = mosaic patches of images below 8x8 (HaloGeom::mos; a wave's pixels then span eight samples, so the epilogue
 // fetches the per-sample row vector per pixel fragment).  Separate instantiations, so that no form carries another's registers
 // (the kernel sits at the SGPR / VGPR limits of two waves per SIMD).
-template <typename T, int NW, bool GN, int NTAP = 9, int MODE = 0>
+// STG (8 waves, no fused GroupNorm): the tap loop in HALF-steps with the two wave groups (waves 0-3 / 4-7 = the two waves of every
+// SIMD) running ONE BARRIER APART — the schedule of igemm_wide.hip applied to the halo loop.  A step is
+//   b ; R_a { issue W(s+PD) ; read the 4 W fragments and pixel fragments 0-3 } ; b ; M_a { 16 MFMAs } ;
+//   b ; R_b { tap 0: issue X(cc+1) ; read pixel fragments 4-7 ; wait for my piece of W(s+1) } ; b ; M_b { 16 MFMAs }
+// and group B executes one barrier more in front of the loop (A one behind it): while one wave of a SIMD issues its 16 MFMAs the
+// other reads fragments and issues LDS-DMA.  In the lock-step loop both waves of a SIMD read at the same moment and then share the
+// matrix pipe at the same moment (asymptote 1.35 PF, fixed cost 26 tap-times, 2.33 GHz held: stall-bound — DESIGN 6c).
+// Hazards, barrier instance n (A: R_a(s) in (4s+1, 4s+2), M_a (4s+2, 4s+3), R_b (4s+3, 4s+4), M_b (4s+4, 4s+5); B one later):
+//   RAW  W(s+1) / X(cc+1) are first read by A after instance 4s+5 (R_a(s+1)); every wave waits for its own pieces before its last
+//        barrier of step s (A: instance 4s+4, B: 4s+5).
+//   WAR  W(s+PD) goes into the slot of W(s-1) (WR = PD+1): its last readers (B, R_a(s-1)) retire their reads before they arrive at
+//        instance 4s; the earliest re-stage (A, R_a(s)) comes after instance 4s+1.  X(cc+1) goes into X(cc-1)'s buffer: last read by
+//        B in R_b of the previous chunk's last step, retired before B arrives at the instance A's R_b of tap 0 waits behind.
+// One accumulator gets one MFMA per step in both loops: results are bit-identical.
+template <typename T, int NW, bool GN, int NTAP = 9, int MODE = 0, bool STG = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
+  static_assert(!STG || (NW == 8 && !GN), "staggered loop: the 8-wave kernel without the fused GroupNorm");
   constexpr bool XB = MODE == 1, MOS = MODE == 2;
   using Cfg = HaloCfg<NW>;
   constexpr int EPC = Elem<T>::EPC;
@@ -95,10 +116,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     tbl[4 * t + 1] = (vn && a.src1) ? (a.map1 ? a.map1[n] : n) * HWs : -1;
     tbl[4 * t + 2] = (vn && a.src2) ? (a.map2 ? a.map2[n] : n) * HWs : -1;
   }
-#pragma unroll
-  for (int i = 0; i < NXL; ++i) {
+  // piece i of this lane: (image of the patch << 20) | pixel offset inside the sample, or -1 (padding)
+  auto piece_code = [&](int i) -> int {
     const int hr = (i * NT + t) >> 2;
-    pp[i] = -1;
+    int code = -1;
     if (i < g.nxl && hr < g.HR) {
       // hr < 2^12 and (hr + 0.5) / hp is at least 0.5 / hp away from an integer: the fp32 product floors exactly
       if constexpr (MOS) {
@@ -107,17 +128,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
         const int hy = (int)(((float)hr + 0.5f) * g.inv_hw), hx = hr - hy * g.hw;
         const int cy = (int)(((float)hy + 0.5f) * g.inv_ch), ry = hy - cy * (th + 1);
         const int cx = (int)(((float)hx + 0.5f) * g.inv_cw), rx = hx - cx * (tw + 1);
-        if (ry > 0 && rx > 0) pp[i] = (((cy << g.lmc) + cx) << 20) | ((ry - 1) * g.W + rx - 1);
+        if (ry > 0 && rx > 0) code = (((cy << g.lmc) + cx) << 20) | ((ry - 1) * g.W + rx - 1);
       } else {
-      const int img = (int)(((float)hr + 0.5f) * g.inv_hp), r = hr - img * g.hp;
-      const int hy = (int)(((float)r + 0.5f) * g.inv_hw), hx = r - hy * g.hw;
-      const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
-      // nearest-2x upsample folded into the gather: halo pixel (iy, ix) of the upsampled image reads source (iy>>1, ix>>1)
-      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-        pp[i] = (img << 20) | (a.upsample ? (iy >> 1) * (g.W >> 1) + (ix >> 1) : iy * g.W + ix);
+        const int img = (int)(((float)hr + 0.5f) * g.inv_hp), r = hr - img * g.hp;
+        const int hy = (int)(((float)r + 0.5f) * g.inv_hw), hx = r - hy * g.hw;
+        const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
+        // nearest-2x upsample folded into the gather: halo pixel (iy, ix) of the upsampled image reads source (iy>>1, ix>>1)
+        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+          code = (img << 20) | (a.upsample ? (iy >> 1) * (g.W >> 1) + (ix >> 1) : iy * g.W + ix);
       }
     }
-  }
+    return code;
+  };
+#pragma unroll
+  for (int i = 0; i < NXL; ++i) pp[i] = piece_code(i);
   // XB (one image per patch = one sample per workgroup): bias + the sample's row vector of this N tile, summed once into LDS (the
   // GroupNorm slot, unused here) while the piece offsets are being formed — the epilogue then reads them at LDS latency instead of
   // paying a global-load round trip (~2.5 k of a ~19 k-cycle epilogue by s_memtime stamps) in front of its first use.
@@ -134,6 +158,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   }
   __syncthreads();
   const char* zero = reinterpret_cast<const char*>(g_zero_page);      // wave-uniform (any 16 zero bytes do)
+  // STG without the buffer-descriptor halo loaders (several images per patch): pp[i] holds the piece's ROW in the tensor of the source
+  // being fetched (sample base + pixel, -1 = padding / no such sample), rebuilt when the chunk stream moves to the next source (at
+  // most twice per tile) — a piece then costs one 64-bit multiply-add instead of an LDS table lookup in front of ~15 VALU (stamps:
+  // 720 cycles per piece in the MFMA block that carries it, tools/stamp_halo.py)
+  constexpr bool XROW = STG && !XB;
+  auto retarget = [&](int which) {
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int code = piece_code(i);
+      int row = -1;
+      if (code >= 0) {
+        const int b = tbl[4 * (code >> 20) + which];
+        if (b >= 0) row = b + (code & 0xFFFFF);
+      }
+      pp[i] = row;
+    }
+  };
+  if constexpr (XROW) retarget(0);
 
   // ---- fused GroupNorm(+SiLU) prologue: y = act(x*scale[n][c] + shift[n][c]) applied IN PLACE on the landed halo ----
   // (one sample per workgroup; every lane transforms exactly the 16-byte chunks it fetched, and skips padding rows,
@@ -184,12 +226,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     xb0 = reinterpret_cast<const T*>(a.src0) + (size_t)s0 * HWs * a.ld0;
     if (a.src1) { const int s1 = __builtin_amdgcn_readfirstlane(a.map1 ? a.map1[n] : n); xb1 = reinterpret_cast<const T*>(a.src1) + (size_t)s1 * HWs * a.ld1; }
     if (a.src2) { const int s2 = __builtin_amdgcn_readfirstlane(a.map2 ? a.map2[n] : n); xb2 = reinterpret_cast<const T*>(a.src2) + (size_t)s2 * HWs * a.ld2; }
+  }
+  if (XB || STG) {                                   // (STG: the W tiles go through the descriptor in every loader mode — no address VALU per issue)
     const int wrow0 = t >> 2;                        // LDS row of the lane's first piece (piece i is 64 rows further when NT == 256)
     wvoff = (epi_wrow(wrow0, false) * a.Ktot + ((t & 3) ^ swz64(wrow0)) * EPC) * (int)sizeof(T);
   }
   auto rsrc_of = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
 
-  auto issue_x = [&](int cc) {                       // cc >= nchunks: chunk cc - nchunks of the 1x1 side source
+  auto issue_x = [&](int cc, int i0 = 0, int i1 = 64) {    // cc >= nchunks: chunk cc - nchunks of the 1x1 side source; pieces [i0, i1)
     const int which = cc >= nchunks ? 2 : (cc >= c0chunks ? 1 : 0);
     if constexpr (XB) {
       // (selected from LOCAL copies: a select between fields of the by-value argument struct becomes a select of their addresses,
@@ -203,6 +247,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       char* xs = smem + (cc & 1) * Cfg::XBUF + wave * 1024;
 #pragma unroll
       for (int i = 0; i < NXL; ++i) {
+        if (i < i0 || i >= i1) continue;
         int pk = pp[i];
         asm volatile("" : "+v"(pk));      // form the offset HERE, once per chunk (hoisted it would cost a register per piece)
         const int voff = pk < 0 ? -1 : pk * ldb + cofs;
@@ -218,11 +263,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     for (int i = 0; i < NXL; ++i) {
       // always NXL instructions (pieces past the halo fetch the zero page into the unused tail of the buffer):
       // the counted vmcnt waits of the tap loop are then compile-time constants
+      if (i < i0 || i >= i1) continue;
       int pk = pp[i];
       asm volatile("" : "+v"(pk));        // decode HERE, once per chunk: hoisted out of the tap loop the fields cost 2 VGPRs per piece
-      const int base = pk < 0 ? -1 : tbl[4 * (pk >> 20) + which];
-      const size_t e = (size_t)(base < 0 ? 0 : base + (pk & 0xFFFFF)) * ld + coff;
-      const char* gp = base < 0 ? zero : reinterpret_cast<const char*>(src + e);
+      int rowi;
+      if constexpr (XROW) rowi = pk;      // already the row of the source in flight
+      else {
+        const int base = pk < 0 ? -1 : tbl[4 * (pk >> 20) + which];
+        rowi = base < 0 ? -1 : base + (pk & 0xFFFFF);
+      }
+      const size_t e = (size_t)(rowi < 0 ? 0 : rowi) * ld + coff;
+      const char* gp = rowi < 0 ? zero : reinterpret_cast<const char*>(src + e);
       __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
     }
     }
@@ -232,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // issue from an opaque copy of t (a handful of VALU per tap) instead of living in VGPRs through the tap loop
   const int wtile0 = ((UP4 ? phase * (a.tiles_n >> 2) : 0) + tile_n) * 128 * a.Ktot;    // element offset of the N tile (up4: [phase][Cout_pad][4 taps * C]); < 2^30 (host check)
   auto issue_w = [&](int cc, int tap, int slot) {
-    if constexpr (XB) {
+    if constexpr (XB || STG) {
       const int so = (wtile0 + tap * Ctot + cc * BKE) * (int)sizeof(T);                  // wave-uniform: scalar offset
       const __amdgpu_buffer_rsrc_t wrs = rsrc_of(a.W);
 #pragma unroll
@@ -309,6 +360,124 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   };
 
   DC_STAMP(1);
+  if constexpr (STG) {
+    const bool grpB = wave >= 4;                       // wave-uniform
+    const int abl = DC_HALO_ABL();                     // 0 outside diagnostic builds
+    int cur_which = 0;
+    issue_x(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue_w(0, i, i);
+    hwait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grpB) __builtin_amdgcn_s_barrier();
+    DC_CLOCK(0);
+    chunk16 wf[TN], xf[TM / 2];
+    // fragment reads as opaque instructions with explicit waits tied to their registers (common.h), MFMA blocks fenced with
+    // sched_barrier: hipcc otherwise moves the MFMAs across the barriers (two s_barrier back to back in the ISA) and re-serialises
+    // the reads.  Addresses: per-lane LDS address of pixel fragment j (8 registers) + a wave-uniform (buffer, tap row) part.
+    const uint32_t lds0 = lds_addr_of(smem);
+    uint32_t xaddr[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xaddr[j] = lds0 + (uint32_t)(joff[j] + xl);
+    const uint32_t waddr = lds_addr_of(Wring) + (uint32_t)woff0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+      const bool side_next = cc + 1 == nchunks && nx > 0;
+      const bool has_next = cc + 1 < nchunks || side_next;
+      const int s0 = cc * NTAP;
+      const uint32_t xbo = (uint32_t)(cc & 1) * Cfg::XBUF;
+      if constexpr (XROW) {               // the halo issued during this chunk is chunk cc + 1's
+        const int wnext = cc + 1 >= nchunks ? 2 : (cc + 1 >= c0chunks ? 1 : 0);
+        if (has_next && wnext != cur_which) { retarget(wnext); cur_which = wnext; }
+      }
+      auto step = [&](auto tapc) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr int ky = UP4 ? (tap >> 1) : tap / 3, kx = UP4 ? (tap & 1) : tap - ky * 3;
+        const uint32_t rowo = xbo + (uint32_t)(((ky + pa) * g.hw + pb) * 64);      // wave-uniform; kx * 64 is the instruction's immediate
+        const uint32_t wso = (uint32_t)((s0 + tap) % WR) * HALO_WST;
+        // ---- half a: reads, then 16 MFMAs with this step's W LDS-DMA after the fourth (an LDS-DMA issued among MFMAs costs the
+        // wave ~60 cycles; issued in front of the fragment reads it held the whole read phase up: 1880 -> 1266 cycles per step
+        // without the instruction, tools/stamp_halo.py ablations) ----
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 2)) {
+        wf[0] = ds_read16_async_off<0>(waddr + wso);
+        wf[1] = ds_read16_async_off<1024>(waddr + wso);
+        wf[2] = ds_read16_async_off<2048>(waddr + wso);
+        wf[3] = ds_read16_async_off<3072>(waddr + wso);
+#pragma unroll
+        for (int j = 0; j < TM / 2; ++j) xf[j] = ds_read16_async_off<kx * 64>(xaddr[j] + rowo);
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 1)) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i][0] = Mma<T>::run(wf[i], xf[0], acc[i][0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int t2 = tap + PD;
+        if (!(abl & 4)) {
+        if (t2 < NTAP) issue_w(cc, t2, (s0 + t2) % WR);
+        else if (side_next) { if (t2 - NTAP < nx) issue_w2(t2 - NTAP, (s0 + t2) % WR); }
+        else if (has_next) issue_w(cc + 1, t2 - NTAP, (s0 + t2) % WR);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 1)) {
+#pragma unroll
+        for (int j = 1; j < TM / 2; ++j)
+#pragma unroll
+          for (int i = 0; i < TN; ++i) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- half b: reads of pixel fragments 4-7; the NEXT chunk's halo pieces ride inside the MFMA block (3x3: two at tap 0, one at
+        // taps 1-5; four-tap form: all at tap 0) ----
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 2)) {
+#pragma unroll
+        for (int j = 0; j < TM / 2; ++j) xf[j] = ds_read16_async_off<kx * 64>(xaddr[TM / 2 + j] + rowo);
+        }
+        // my piece(s) of W(s+1) must be in before my last barrier of this step (they are first read right behind the first barrier of
+        // the next step, by the other group first).  Issue order per wave: ... W(s+1) | X pieces of tap s-2 | W(s+2) | X pieces of tap
+        // s-1 | W(s+3) | this wait: the younger groups that may stay in flight are the W groups that exist and the X pieces of the two
+        // previous taps.  At the chunk's last tap no X piece is younger: the whole next halo is in.
+        constexpr int XP_A = UP4 ? (tap == 1 ? NXL : 0) : (tap == 1 ? 2 : (tap >= 2 && tap <= 6 ? 1 : 0));     // pieces issued at tap - 1
+        constexpr int XP_B = UP4 ? (tap == 2 ? NXL : 0) : (tap == 2 ? 2 : (tap >= 3 && tap <= 7 ? 1 : 0));     // pieces issued at tap - 2
+        if (has_next) {
+          if (tap == NTAP - 1 && side_next && nx < PD) hwait_vmcnt<0>();      // fewer side-source W tiles than the prefetch distance
+          else hwait_vmcnt<(PD - 1) * WLD + XP_A + XP_B>();
+        } else {
+          constexpr int left = NTAP - 1 - tap;          // W groups behind this step's
+          if constexpr (left > 0) hwait_vmcnt<((left - 1) < (PD - 1) ? (left - 1) : (PD - 1)) * WLD>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 1)) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i][TM / 2] = Mma<T>::run(wf[i], xf[0], acc[i][TM / 2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next && !(abl & 12)) {
+          if constexpr (UP4) { if (tap == 0) issue_x(cc + 1); }
+          else if constexpr (tap == 0) issue_x(cc + 1, 0, 2);
+          else if constexpr (tap <= 5) issue_x(cc + 1, tap + 1, tap + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 1)) {
+#pragma unroll
+        for (int j = 1; j < TM / 2; ++j)
+#pragma unroll
+          for (int i = 0; i < TN; ++i) acc[i][TM / 2 + j] = Mma<T>::run(wf[i], xf[j], acc[i][TM / 2 + j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
+      if constexpr (NTAP == 9) { step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{}); }
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();           // the groups are level again (the side-source steps below run in lock-step)
+    DC_CLOCK(1);
+  } else {
   // ---- tap loop: the 9 taps of a channel chunk are unrolled, so tap offsets, ring slots and every counted vmcnt
   // are compile-time constants (the rolled loop spent ~300 cycles of scalar control per 512-cycle MFMA block).
   // W(s) sits in ring slot s % WR, prefetch distance PD; X(cc+1) is issued at tap 0 behind W(s+PD). ----
@@ -320,7 +489,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < NXL; ++i) xform(0, i);
   }
-  constexpr int FLY = (PD - 1) * WLD;                // W(s+1) .. W(s+PD-1)
+  constexpr int FLYL = (PD - 1) * WLD;               // W(s+1) .. W(s+PD-1)
   DC_CLOCK(0);
   for (int cc = 0; cc < nchunks; ++cc) {
     // "has_next": another X chunk and more W groups follow this chunk — the next 3x3 chunk, or the first chunk of the
@@ -334,8 +503,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       // W(s) (and X(cc) when tap == 0) must have landed.  Younger LDS-DMA groups that may stay in flight: W(s+1) ..
       // W(s+PD-1) and, for tap in 1..PD, the NXL loads of X(cc+1) issued at tap 0; the last chunk has fewer W groups left.
       if (has_next) {
-        if (tap >= 1 && tap <= PD) hwait_vmcnt<FLY + NXL>();
-        else hwait_vmcnt<FLY>();
+        if (tap >= 1 && tap <= PD) hwait_vmcnt<FLYL + NXL>();
+        else hwait_vmcnt<FLYL>();
       } else {
         constexpr int left = NTAP - 1 - tap;        // W groups behind this one
         hwait_vmcnt<(left < PD - 1 ? left : PD - 1) * WLD>();
@@ -361,6 +530,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   }
 
   DC_CLOCK(1);
+  }
+  constexpr int FLY = (PD - 1) * WLD;
   // ---- 1x1 side source (a ResNet's conv_shortcut folded into its conv2): nx steps of ONE tap (the centre) each.  X2(0)
   // and W2(0 .. PD-1) were issued inside the last 3x3 chunk; a step needs a fresh halo chunk per 32 MFMAs, so from the second
   // step on the loads of the previous step are simply drained (vmcnt 0): ~2 k exposed cycles per step, against the whole
@@ -678,7 +849,24 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
   if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 1> : conv3_halo_kernel<T, NW, false, 9, 1>;
-  if constexpr (NW == 8) { if (g.mos) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 2> : conv3_halo_kernel<T, NW, false, 9, 2>; }
+  if constexpr (NW == 8) {
+    if (g.mos) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 2> : conv3_halo_kernel<T, NW, false, 9, 2>;
+    // staggered wave groups (STG) unless DCAMD_HALO_NO_STAG (read per call: A/B runs in one process)
+    // (the four-tap upsample form stays on the lock-step loop: its whole next halo would ride in one MFMA block — measured slower)
+    if (!up4 && !a0.gn_scale && !getenv("DCAMD_HALO_NO_STAG") && (long long)a.tiles_n * 128 * a.Ktot * (long long)sizeof(T) < (1LL << 31)) {
+      const int mode = g.mos ? 2 : (g.xbuf ? 1 : 0);
+      static bool stg_attr[3] = {false, false, false};
+      switch (mode) {
+        case 0: kern = conv3_halo_kernel<T, NW, false, 9, 0, true>; break;
+        case 1: kern = conv3_halo_kernel<T, NW, false, 9, 1, true>; break;
+        default: kern = conv3_halo_kernel<T, NW, false, 9, 2, true>; break;
+      }
+      if (!stg_attr[mode]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        stg_attr[mode] = true;
+      }
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
 }
