@@ -407,20 +407,34 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
 #pragma unroll
         for (int j = 0; j < TM / 2; ++j) xf[j] = ds_read16_async_off<kx * 64>(xaddr[j] + rowo);
         }
+        constexpr int t2 = tap + PD;
+#ifndef DC_STG_W_IN_M     // the W tile's LDS-DMA goes out in the read phase, behind the fragment reads (inside the MFMA block: 13.6 vs 13.2 ms)
+        if (!(abl & 4)) {
+        if (t2 < NTAP) issue_w(cc, t2, (s0 + t2) % WR);
+        else if (side_next) { if (t2 - NTAP < nx) issue_w2(t2 - NTAP, (s0 + t2) % WR); }
+        else if (has_next) issue_w(cc + 1, t2 - NTAP, (s0 + t2) % WR);
+        }
+#endif
+#ifdef DC_STG_WAIT_FIRST  // experiment: retire the fragment reads in front of the barrier instead of behind it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+        __builtin_amdgcn_s_barrier();
+#else
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 1)) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) acc[i][0] = Mma<T>::run(wf[i], xf[0], acc[i][0]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int t2 = tap + PD;
+#ifdef DC_STG_W_IN_M
         if (!(abl & 4)) {
         if (t2 < NTAP) issue_w(cc, t2, (s0 + t2) % WR);
         else if (side_next) { if (t2 - NTAP < nx) issue_w2(t2 - NTAP, (s0 + t2) % WR); }
         else if (has_next) issue_w(cc + 1, t2 - NTAP, (s0 + t2) % WR);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 1)) {
 #pragma unroll
@@ -442,7 +456,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
         // s-1 | W(s+3) | this wait: the younger groups that may stay in flight are the W groups that exist and the X pieces of the two
         // previous taps.  At the chunk's last tap no X piece is younger: the whole next halo is in.
         constexpr int XP_A = UP4 ? (tap == 1 ? NXL : 0) : (tap == 1 ? 2 : (tap >= 2 && tap <= 6 ? 1 : 0));     // pieces issued at tap - 1
+#ifndef DC_STG_X_IN_M     // the halo pieces go out in the read phase, in front of this wait (inside the MFMA block — DC_STG_X_IN_M — they idle the
+                          // matrix pipe for the ~470 cycles an HBM-bound piece takes to issue: conv3_halo<8w> 15.3 vs 13.9 ms per cfg2 step)
+        constexpr int XP_C = UP4 ? (tap == 0 ? NXL : 0) : (tap == 0 ? 2 : (tap <= 5 ? 1 : 0));               // pieces issued at this tap
+        if (has_next && !(abl & 12)) {
+          if constexpr (UP4) { if (tap == 0) issue_x(cc + 1); }
+          else if constexpr (tap == 0) issue_x(cc + 1, 0, 2);
+          else if constexpr (tap <= 5) issue_x(cc + 1, tap + 1, tap + 2);
+        }
+        constexpr int XP_B = XP_C + (UP4 ? (tap == 2 ? NXL : 0) : (tap == 2 ? 2 : (tap >= 3 && tap <= 7 ? 1 : 0)));
+#else
         constexpr int XP_B = UP4 ? (tap == 2 ? NXL : 0) : (tap == 2 ? 2 : (tap >= 3 && tap <= 7 ? 1 : 0));     // pieces issued at tap - 2
+#endif
         if (has_next) {
           if (tap == NTAP - 1 && side_next && nx < PD) hwait_vmcnt<0>();      // fewer side-source W tiles than the prefetch distance
           else hwait_vmcnt<(PD - 1) * WLD + XP_A + XP_B>();
@@ -450,19 +475,26 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
           constexpr int left = NTAP - 1 - tap;          // W groups behind this step's
           if constexpr (left > 0) hwait_vmcnt<((left - 1) < (PD - 1) ? (left - 1) : (PD - 1)) * WLD>();
         }
+#ifdef DC_STG_WAIT_FIRST
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+        __builtin_amdgcn_s_barrier();
+#else
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 1)) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) acc[i][TM / 2] = Mma<T>::run(wf[i], xf[0], acc[i][TM / 2]);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DC_STG_X_IN_M
         if (has_next && !(abl & 12)) {
           if constexpr (UP4) { if (tap == 0) issue_x(cc + 1); }
           else if constexpr (tap == 0) issue_x(cc + 1, 0, 2);
           else if constexpr (tap <= 5) issue_x(cc + 1, tap + 1, tap + 2);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 1)) {
 #pragma unroll
