@@ -117,9 +117,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     tbl[4 * t + 2] = (vn && a.src2) ? (a.map2 ? a.map2[n] : n) * HWs : -1;
   }
   // piece i of this lane: (image of the patch << 20) | pixel offset inside the sample, or -1 (padding)
-  auto piece_code = [&](int i) -> int {
+  auto piece_code = [&](int i, int* col = nullptr) -> int {
     const int hr = (i * NT + t) >> 2;
     int code = -1;
+    if (col) *col = 0;
     if (i < g.nxl && hr < g.HR) {
       // hr < 2^12 and (hr + 0.5) / hp is at least 0.5 / hp away from an integer: the fp32 product floors exactly
       if constexpr (MOS) {
@@ -128,11 +129,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
         const int hy = (int)(((float)hr + 0.5f) * g.inv_hw), hx = hr - hy * g.hw;
         const int cy = (int)(((float)hy + 0.5f) * g.inv_ch), ry = hy - cy * (th + 1);
         const int cx = (int)(((float)hx + 0.5f) * g.inv_cw), rx = hx - cx * (tw + 1);
+        if (col) *col = hx;
         if (ry > 0 && rx > 0) code = (((cy << g.lmc) + cx) << 20) | ((ry - 1) * g.W + rx - 1);
       } else {
         const int img = (int)(((float)hr + 0.5f) * g.inv_hp), r = hr - img * g.hp;
         const int hy = (int)(((float)r + 0.5f) * g.inv_hw), hx = r - hy * g.hw;
         const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
+        if (col) *col = hx;
         // nearest-2x upsample folded into the gather: halo pixel (iy, ix) of the upsampled image reads source (iy>>1, ix>>1)
         if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
           code = (img << 20) | (a.upsample ? (iy >> 1) * (g.W >> 1) + (ix >> 1) : iy * g.W + ix);
@@ -140,8 +143,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     }
     return code;
   };
+  // chunk swizzle of the halo image (conv3_halo.h, HaloGeom::sws): the 16-byte slot p & 3 of LDS row p >> 2 holds the row's LOGICAL chunk
+  // (p & 3) ^ 2 * bit(sws) of the row's halo column.  LDS-DMA fixes the slot a lane writes, so the lane fetches the other chunk: one bit
+  // per piece, carried in bit 30 of the piece's code (these kernels have no register to spare).
+  // The staggered loop keeps the UN-swizzled image: its eight reads of a read phase then share one address add per tap row (the column
+  // offset is the instruction's immediate), with the swizzle every read needs its own — measured 13.3 -> 13.8 ms per cfg2 step for
+  // conv3_halo<8w>, while the conflicts it removes (40 % of the LDS cycles by SQ_LDS_BANK_CONFLICT) cost that loop no time.
+  constexpr bool SWP = !STG;
 #pragma unroll
-  for (int i = 0; i < NXL; ++i) pp[i] = piece_code(i);
+  for (int i = 0; i < NXL; ++i) {
+    int col;
+    pp[i] = piece_code(i, &col);
+    if constexpr (SWP) { if (pp[i] >= 0) pp[i] |= ((col >> g.sws) & 1) << 30; }
+  }
+  auto sw_of = [&](int pk) -> int { if constexpr (SWP) return (pk >> 30) & 1; else return 0; };
+  constexpr int PKMASK = SWP ? 0x3FFFFFFF : -1;
   // XB (one image per patch = one sample per workgroup): bias + the sample's row vector of this N tile, summed once into LDS (the
   // GroupNorm slot, unused here) while the piece offsets are being formed — the epilogue then reads them at LDS latency instead of
   // paying a global-load round trip (~2.5 k of a ~19 k-cycle epilogue by s_memtime stamps) in front of its first use.
@@ -192,11 +208,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     __syncthreads();
   }
   auto xform = [&](int ccx, int i) {
-    if (i < g.nxl && pp[i] >= 0 && tbl[4 * (pp[i] >> 20)] >= 0) {
+    if (i < g.nxl && pp[i] >= 0 && tbl[4 * ((pp[i] & PKMASK) >> 20)] >= 0) {
       chunk16* p = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (i * NT + t) * 16);
       float f[EPC];
       chunk_to_f<T>(*p, f);
-      const float* sc = gnp + ccx * BKE + xlx * EPC;
+      const float* sc = gnp + ccx * BKE + (xlx ^ (sw_of(pp[i]) << 1)) * EPC;
       const float* sh = sc + Ctot;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
         if (i < i0 || i >= i1) continue;
         int pk = pp[i];
         asm volatile("" : "+v"(pk));      // form the offset HERE, once per chunk (hoisted it would cost a register per piece)
-        const int voff = pk < 0 ? -1 : pk * ldb + cofs;
+        const int voff = pk < 0 ? -1 : (pk & PKMASK) * ldb + (cofs ^ (sw_of(pk) << 5));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(xs + i * (NT * 16)), 16, voff, 0, 0, 0);
       }
       return;
@@ -269,10 +285,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       int rowi;
       if constexpr (XROW) rowi = pk;      // already the row of the source in flight
       else {
-        const int base = pk < 0 ? -1 : tbl[4 * (pk >> 20) + which];
+        const int base = pk < 0 ? -1 : tbl[4 * ((pk & PKMASK) >> 20) + which];
         rowi = base < 0 ? -1 : base + (pk & 0xFFFFF);
       }
-      const size_t e = (size_t)(rowi < 0 ? 0 : rowi) * ld + coff;
+      const size_t e = (size_t)(rowi < 0 ? 0 : rowi) * ld + (coff ^ (sw_of(pk) << 1) * EPC);
       const char* gp = rowi < 0 ? zero : reinterpret_cast<const char*>(src + e);
       __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(xs + i * (NT * 16)), 16, 0, 0);
     }
@@ -322,7 +338,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // ---- fragment read addresses: per-lane part (one register each) + wave-uniform part per fragment (SGPRs) ----
   // pixel p = wm*128 + j*16 + lr: the lr bits never carry into the bit fields set by j (tile widths are >= 8 and a
   // power of two), so the halo offset splits into f(lr, lq) + f(j); cout fragment i is 16 rows = 1024 B further.
-  const int xl = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64 + lq * 16;
+  // per-lane part, one per swizzle variant: the chunk slot of a pixel fragment's row depends on bit sws of its halo column
+  // X = (lane's column inside the fragment) + kx (+ the fragment's cell column in a mosaic: odd cells for odd j, + the phase's pb in
+  // the four-tap form) — variant k = what is added to the lane's column (mosaic: only its parity counts)
+  constexpr int NV = 3;
+  int xlv[NV];
+  {
+    const int xx = lr & ((tw < 16 ? tw : 16) - 1);
+    const int rowpart = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) xlv[k] = rowpart + ((lq ^ (SWP ? (((xx + k + (UP4 ? pb : 0)) >> g.sws) & 1) << 1 : 0)) << 4);
+  }
   int joff[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -342,7 +368,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // one tap of one channel chunk: W fragments, then the X fragments in two halves that share registers (all eight at once
   // need 16 more VGPRs than this kernel has: a spill inside the tap loop is reloaded behind vmcnt(0), which drains the
   // LDS-DMA ring); MFMAs in j-major order.  The sched_barrier keeps hipcc from hoisting the second half's reads.
-  auto mma_tap = [&](const char* Wst, const char* Xb, int tapoff) {
+  auto mma_tap = [&](const char* Wst, const char* Xb, int tapoff, auto kxc) {
+    constexpr int kx = decltype(kxc)::value;      // swizzle variant of the tap's column offset
     chunk16 wf[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const chunk16*>(Wst + woff0 + i * 1024);
@@ -350,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     for (int h = 0; h < 2; ++h) {
       chunk16 xf[TM / 2];
 #pragma unroll
-      for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[h * (TM / 2) + j]) + xl);
+      for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[h * (TM / 2) + j]) + xlv[MOS ? ((kx + j) & 1) : kx]);
 #pragma unroll
       for (int j = 0; j < TM / 2; ++j)
 #pragma unroll
@@ -376,9 +403,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     // sched_barrier: hipcc otherwise moves the MFMAs across the barriers (two s_barrier back to back in the ISA) and re-serialises
     // the reads.  Addresses: per-lane LDS address of pixel fragment j (8 registers) + a wave-uniform (buffer, tap row) part.
     const uint32_t lds0 = lds_addr_of(smem);
-    uint32_t xaddr[TM];
+    uint32_t xaddr[TM];                   // per-lane LDS address of pixel fragment j (no swizzle here: xlv[0] = xlv[1] = xlv[2])
 #pragma unroll
-    for (int j = 0; j < TM; ++j) xaddr[j] = lds0 + (uint32_t)(joff[j] + xl);
+    for (int j = 0; j < TM; ++j) xaddr[j] = lds0 + (uint32_t)(joff[j] + xlv[0]);
     const uint32_t waddr = lds_addr_of(Wring) + (uint32_t)woff0;
     for (int cc = 0; cc < nchunks; ++cc) {
       const bool side_next = cc + 1 == nchunks && nx > 0;
@@ -552,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       const char* Wst = Wring + ((s0 + tap) % WR) * HALO_WST;
       constexpr int ky = UP4 ? (tap >> 1) : tap / 3, kx = UP4 ? (tap & 1) : tap - ky * 3;
       const int tapoff = ((ky + pa) * g.hw + kx + pb) * 64;       // pa = pb = 0 for the 3x3 conv
-      mma_tap(Wst, Xb, tapoff);
+      mma_tap(Wst, Xb, tapoff, IC<kx>{});
       // X(cc+1) was issued at tap 0 and this lane's own pieces were waited for at tap PD+1: from then on transform
       // one piece per tap, behind this tap's MFMAs (other waves read the buffer only after the next chunk's barrier)
       if (gn && tap > PD && has_next) xform(cc + 1, tap > PD ? tap - PD - 1 : 0);
@@ -579,7 +606,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       const char* Xb = smem + ((nchunks + e) & 1) * Cfg::XBUF;
       const char* Wst = Wring + ((NSm + e) % WR) * HALO_WST;
       const int tapoff = (g.hw + 1) * 64;              // centre tap
-      mma_tap(Wst, Xb, tapoff);
+      mma_tap(Wst, Xb, tapoff, IC<1>{});
     }
   }
 
@@ -867,6 +894,7 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
     g.inv_ch = 1.0f / (float)(th + 1); g.inv_cw = 1.0f / (float)(tw + 1);
   }
   g.inv_hp = g.hp ? 1.0f / (float)g.hp : 0.f; g.inv_hw = 1.0f / (float)g.hw;
+  g.sws = (g.ltw < 4 ? g.ltw : 4) - 2;     // tw >= 16: 2, 8: 1, 4 (mosaic): 0
   static const bool no_xbuf = getenv("DCAMD_HALO_NO_XBUF") != nullptr;
   {
     const long long hws = (long long)(a.upsample ? (g.H >> 1) * (g.W >> 1) : g.H * g.W);
@@ -965,7 +993,7 @@ static int launch_thin(const IgemmArgs& a0, int n_img, hipStream_t s) {
   g.ltw = ilog2(tw); g.lth = ilog2(th); g.lni = ilog2(ni);
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = ni * g.hp;
-  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.xbuf = 0;
+  g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.xbuf = 0; g.sws = 0;     // (the thin kernel keeps its own un-swizzled image)
   g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + ThinCfg::NT - 1) / ThinCfg::NT;
   if (g.nxl > ThinCfg::NXL) { dc_set_error("conv3_thin: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }

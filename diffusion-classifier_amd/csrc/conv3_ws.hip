@@ -118,6 +118,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     // =============================================== LOADER TEAM ===============================================
     // piece i of lane tl: LDS position i * 256 + tl -> halo row >> 2, 16-byte chunk & 3 (the image is not swizzled)
     int pp[NXL];                                // pixel offset inside the sample, -1 = padding
+    int hsw = 0;                                // chunk swizzle (HaloGeom::sws): bit i = this lane's slot of piece i holds logical chunk xlx ^ 2
     const int xlx = tl & 3;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
         // hr < 2^12 and (hr + 0.5) / hw is at least 0.5 / hw away from an integer: the fp32 product floors exactly
         const int hy = (int)(((float)hr + 0.5f) * g.inv_hw), hx = hr - hy * g.hw;
         const int iy = ty * th + hy - 1, ix = tx * tw + hx - 1;
+        hsw |= ((hx >> g.sws) & 1) << i;
         if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) pp[i] = iy * g.W + ix;
       }
     }
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
       for (int i = 0; i < NXL; ++i) {
         // always NXL instructions (pieces past the halo are out of range: zeros into the unused tail): the counted waits stay constants
         const int pk = pp[i];
-        const int voff = pk < 0 ? -1 : pk * ldb + cofs;
+        const int voff = pk < 0 ? -1 : pk * ldb + (cofs ^ (((hsw >> i) & 1) << 5));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(xs + i * (NTL * 16)), 16, voff, 0, 0, 0);
       }
     };
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     };
     auto xform = [&](int ccx, int i) {
       if (pp[i] >= 0 && !(abl & 8)) {
-        chunk16* q = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (i * NTL + tl) * 16);
+        // the lane transforms the slot that holds logical chunk xlx of its row (its own, or its neighbour's two lanes over — same wave,
+        // same row, so the same vmcnt wait and the same padding test cover it): the affine registers stay one chunk's
+        chunk16* q = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (((i * NTL + tl) * 16) ^ (((hsw >> i) & 1) << 5)));
         float f[EPC];
         chunk_to_f<T>(*q, f);
 #pragma unroll
@@ -262,7 +266,13 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
   const int wm = cw >> 1, wn = cw & 1;          // 2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   // fragment read addresses: per-lane part + wave-uniform part per fragment (SGPRs); pixel p = wm*128 + j*16 + lr
-  const int xl = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64 + lq * 16;
+  int xlv[3];                                   // per-lane part per column offset of the tap (chunk swizzle: conv3_halo.h, HaloGeom::sws)
+  {
+    const int xx = lr & ((tw < 16 ? tw : 16) - 1);
+    const int rowpart = ((lr >> g.ltw) * g.hw + (lr & (tw - 1))) * 64;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xlv[k] = rowpart + ((lq ^ ((((xx + k) >> g.sws) & 1) << 1)) << 4);
+  }
   int joff[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -277,7 +287,8 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // one tap of one channel chunk: W fragments, then the X fragments in two halves; MFMAs in j-major order (the 4-wave kernel's order)
-  auto mma_tap = [&](const char* Wst, const char* Xb, int tapoff) {
+  auto mma_tap = [&](const char* Wst, const char* Xb, int tapoff, auto kxc) {
+    constexpr int kx = decltype(kxc)::value;
     if (abl & 32) return;
     chunk16 wf[TN];
 #pragma unroll
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     for (int h = 0; h < 2; ++h) {
       chunk16 xf[TM / 2];
 #pragma unroll
-      for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[h * (TM / 2) + j]) + xl);
+      for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const chunk16*>(Xb + (tapoff + joff[h * (TM / 2) + j]) + xlv[kx]);
 #ifdef DC_STAMPS
       if (abl & 1) {                              // timing only: the fragments are read, nothing is multiplied
 #pragma unroll
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
       __builtin_amdgcn_s_barrier();
       const char* Wst = Wring + ((s0c + tap) % WR) * HALO_WST;
       constexpr int ky = tap / 3, kx = tap - ky * 3;
-      mma_tap(Wst, Xb, (ky * g.hw + kx) * 64);
+      mma_tap(Wst, Xb, (ky * g.hw + kx) * 64, IC<kx>{});
     };
     step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
   }
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     const int NSm = nchunks * NTAP;
     for (int e = 0; e < nx; ++e) {
       __builtin_amdgcn_s_barrier();
-      mma_tap(Wring + ((NSm + e) % WR) * HALO_WST, smem + ((nchunks + e) & 1) * Cfg::XBUF, (g.hw + 1) * 64);     // centre tap
+      mma_tap(Wring + ((NSm + e) % WR) * HALO_WST, smem + ((nchunks + e) & 1) * Cfg::XBUF, (g.hw + 1) * 64, IC<1>{});     // centre tap
     }
   }
   DC_STAMP(2);
@@ -1126,6 +1137,7 @@ static int launch_ws(const IgemmArgs& a0, int n_img, hipStream_t s) {
   g.tiles_x = g.W / tw; g.tiles_y = g.H / th;
   g.hw = tw + 2; g.hp = (th + 2) * g.hw; g.HR = g.hp;
   g.mos = 0; g.lmc = 0; g.inv_ch = g.inv_cw = 0.f; g.xbuf = 1;
+  g.sws = 2;          // fragments of 16 pixels in a row (tw >= 16); the opt-in persistent kernels below keep the un-swizzled image
   g.inv_hp = 1.0f / (float)g.hp; g.inv_hw = 1.0f / (float)g.hw;
   g.nxl = (g.HR * 4 + Cfg::NTL - 1) / Cfg::NTL;
   if (g.nxl > Cfg::NXL || g.nxl < 3) { dc_set_error("conv3_ws: halo of %d rows does not fit", g.HR); return DC_ERR_SHAPE; }
