@@ -11,6 +11,7 @@
 // The fp32 kernel of attention.hip stays the path for f32 (exact) and for shapes outside
 // L % 16 == 0, d % 32 == 0.
 #include <stdlib.h>
+#include <type_traits>
 #include "igemm_common.h"
 
 struct AttnMArgs {
@@ -335,6 +336,8 @@ template <> struct Mma16<_Float16> {
   }
 };
 
+// (two workgroups per CU.  Three — launch bounds of 168 registers — were measured slower for D = 64: 10 spilled registers, 442 against
+//  507 TFLOP/s on the DiT-B/4 shape, tools/bench_attention.py)
 template <typename T, int D>
 __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a) {
   constexpr int KB = D <= 32 ? 128 : (D <= 64 ? 64 : 32);     // keys per block: sized so that scores + staged K/V fit the register file
@@ -375,6 +378,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
     for (int dt = 0; dt < NDT; ++dt) O[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float sc2 = a.scale * 1.4426950408889634f;            // scores in log2 units
+  // The softmax keeps the running max of the RAW scores (the scale is positive: same arg max) and forms p = exp2(s * sc2 - m * sc2) as ONE
+  // fused multiply-add per score in front of v_exp_f32; keys past L are masked only in a block that holds some (the DiT token counts have
+  // none).  Per 64-key block and wave the kernel issues 34 v_exp_f32 (16 cycles each) and ~120 other VALU instructions against 512 cycles
+  // of MFMA; the scale multiply, the subtraction and the per-score select were another ~90 (467 -> 507 TFLOP/s f16, 529 -> 578 bf16 on
+  // 1024 tokens x 12 heads x 64; the serial MFMA -> max -> shuffle -> exp -> pack -> MFMA chain of a wave is what remains).
 
   chunk16 ks[NST], vs[NST];
   auto fetch = [&](int k0) {
@@ -402,7 +410,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
   __syncthreads();
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const int nblk = (L + KB - 1) / KB;
-  for (int ib = 0; ib < nblk; ++ib) {
+  // one key block; RAGGED: it holds keys past L (only the last block of a sequence that is not a multiple of KB: its own copy of the
+  // body behind the loop — as a condition inside one body hipcc turns the mask back into per-score selects)
+  auto run_block = [&](int ib, auto raggedc) {
+    constexpr bool ragged = decltype(raggedc)::value;
     const int k0 = ib * KB, buf = ib & 1;
     if (ib + 1 < nblk) fetch(k0 + KB);                        // lands under this block's MFMAs
     const T* Kb = Kl + buf * KB * PITCH;
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
       f32x4 S[NKT];
-      float mx = m[qt];
+      float mx = m[qt];                                       // running max of the raw scores
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -419,17 +430,19 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
           const chunk16 kf = *reinterpret_cast<const chunk16*>(Kb + (kt * 16 + lr) * PITCH + kb * 32 + lq * 8);
           acc = Mma<T>::run(kf, qf[qt][kb], acc);             // rows = keys, column = query
         }
+        if constexpr (ragged) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool kvalid = k0 + kt * 16 + lq * 4 + r < L;  // keys past L never win the max nor add to the sum
-          acc[r] = kvalid ? acc[r] * sc2 : -INFINITY;
-          mx = fmaxf(mx, acc[r]);
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + lq * 4 + r >= L) acc[r] = -INFINITY;     // keys past L never win the max nor add to the sum
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[r]);
         S[kt] = acc;
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float corr = __builtin_amdgcn_exp2f(m[qt] - mx);  // exp2(-inf) = 0 on the first block
+      const float nms = -mx * sc2;
+      const float corr = __builtin_amdgcn_exp2f(__builtin_fmaf(m[qt], sc2, nms));    // exp2(-inf) = 0 on the first block
       m[qt] = mx;
       float ps = 0.f;
       s16x4 P[NKT];
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
       for (int kt = 0; kt < NKT; ++kt) {
         float pv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(S[kt][r] - mx); ps += pv[r]; }
+        for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], sc2, nms)); ps += pv[r]; }
         typename Elem<T>::vec4 pk;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pk[r] = Elem<T>::from_f(pv[r]);
@@ -474,7 +487,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
     }
     if (ib + 1 < nblk) stash(buf ^ 1);
     __syncthreads();
-  }
+  };
+  const int nfull = L / KB;
+  for (int ib = 0; ib < nfull; ++ib) run_block(ib, std::false_type{});
+  if (nfull < nblk) run_block(nfull, std::true_type{});
 #pragma unroll
   for (int qt = 0; qt < NQT; ++qt) {
     const int qi = q0 + qt * 16 + lr;
