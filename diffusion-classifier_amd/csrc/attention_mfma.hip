@@ -338,6 +338,34 @@ template <> struct Mma16<_Float16> {
 
 // (two workgroups per CU.  Three — launch bounds of 168 registers — were measured slower for D = 64: 10 spilled registers, 442 against
 //  507 TFLOP/s on the DiT-B/4 shape, tools/bench_attention.py)
+// Reductions over the four lanes that share a query column in the transposed-score form (lanes lr, lr + 16, lr + 32, lr + 48) on the
+// VALU: v_permlane16_swap_b32 exchanges the odd 16-lane rows of one operand with the even rows of the other, v_permlane32_swap_b32 the
+// upper half of one with the lower half of the other — with both operands the same register the two results are "rows 0 0 2 2" /
+// "rows 1 1 3 3" and "lower lower" / "upper upper", so an op over each pair is the xor-16 / xor-32 butterfly.  The ds_bpermute shuffles
+// these replace were four LDS round trips per query tile and key block in front of the exponentials.
+// (as instructions, not through __builtin_amdgcn_permlane{16,32}_swap: hipcc 7.2 folds the builtin's two results into one once they meet in
+//  an add or a max — it emitted v_add_f32 v, a0, a0 for a0 + a1, with the same or with different operands — which the hardware does not
+//  do: tools/dev/permlane_probe.hip prints what the instruction returns.  The two wait states in front cover a VALU write of the
+//  operands, as the compiler places them in front of its own.)
+template <bool WIDE> static __device__ __forceinline__ void lane_swap(float x, float& lo, float& hi) {
+  unsigned u = __builtin_bit_cast(unsigned, x), v = u;
+  if constexpr (WIDE) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(v));
+  else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u), "+v"(v));
+  lo = __builtin_bit_cast(float, u); hi = __builtin_bit_cast(float, v);
+}
+static __device__ __forceinline__ float col4_max(float x) {
+  float a, b;
+  lane_swap<false>(x, a, b);
+  lane_swap<true>(fmaxf(a, b), a, b);
+  return fmaxf(a, b);
+}
+static __device__ __forceinline__ float col4_sum(float x) {
+  float a, b;
+  lane_swap<false>(x, a, b);
+  lane_swap<true>(a + b, a, b);
+  return a + b;
+}
+
 template <typename T, int D>
 __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a) {
   constexpr int KB = D <= 32 ? 128 : (D <= 64 ? 64 : 32);     // keys per block: sized so that scores + staged K/V fit the register file
@@ -439,8 +467,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[r]);
         S[kt] = acc;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = col4_max(mx);
       const float nms = -mx * sc2;
       const float corr = __builtin_amdgcn_exp2f(__builtin_fmaf(m[qt], sc2, nms));    // exp2(-inf) = 0 on the first block
       m[qt] = mx;
@@ -456,9 +483,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
         for (int r = 0; r < 4; ++r) pk[r] = Elem<T>::from_f(pv[r]);
         P[kt] = __builtin_bit_cast(s16x4, pk);
       }
-      ps += __shfl_xor(ps, 16, 64);
-      ps += __shfl_xor(ps, 32, 64);
-      l[qt] = l[qt] * corr + ps;
+      l[qt] = l[qt] * corr + ps;                              // per-lane partial row sum (corr is the same in the column's four lanes): reduced once, behind the loop
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         f32x4 acc = O[qt][dt];
@@ -494,8 +519,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_t_kernel(const FlashArgs a)
 #pragma unroll
   for (int qt = 0; qt < NQT; ++qt) {
     const int qi = q0 + qt * 16 + lr;
+    const float inv = 1.0f / col4_sum(l[qt]);                 // (all lanes take part in the swaps: before the bounds test)
     if (qi >= L) continue;
-    const float inv = 1.0f / l[qt];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
       typename Elem<T>::vec4 o;
@@ -603,27 +628,26 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const FlashArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool kvalid = kt * 16 + lq * 4 + r < L;
-        acc[r] = kvalid ? acc[r] * sc2 : -INFINITY;
+        acc[r] = kvalid ? acc[r] : -INFINITY;                 // raw scores: the scale is positive, it enters with the max below
         mx = fmaxf(mx, acc[r]);
       }
       S[kt] = acc;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = col4_max(mx);
+    const float nms = -mx * sc2;
     float ps = 0.f;
     s16x4 P[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       float pv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(S[kt][r] - mx); ps += pv[r]; }
+      for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], sc2, nms)); ps += pv[r]; }
       typename Elem<T>::vec4 pk;
 #pragma unroll
       for (int r = 0; r < 4; ++r) pk[r] = Elem<T>::from_f(pv[r]);
       P[kt] = __builtin_bit_cast(s16x4, pk);
     }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
+    ps = col4_sum(ps);
     const float inv = __builtin_amdgcn_rcpf(ps);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
