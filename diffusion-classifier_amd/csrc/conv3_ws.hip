@@ -234,6 +234,9 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
           hwait_vmcnt<(left < PD - 1 ? left : PD - 1) * WLD>();
         }
         if (GN && tap == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my in-place writes of this chunk are in LDS
+#ifdef DC_WS_ROWBAR_ABL   // diagnostic builds, timing only (the W ring is then racy): one barrier per tap ROW instead of one per tap
+        if (tap % 3 == 0)
+#endif
         __builtin_amdgcn_s_barrier();
         constexpr int t2 = tap + PD;              // the W group to issue now: s + PD
         if (t2 < NTAP) issue_w(cc, t2, (s0c + t2) % WR);
@@ -321,6 +324,9 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
     const char* Xb = smem + (cc & 1) * Cfg::XBUF;
     auto step = [&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
+#ifdef DC_WS_ROWBAR_ABL
+      if (tap % 3 == 0)
+#endif
       __builtin_amdgcn_s_barrier();
       const char* Wst = Wring + ((s0c + tap) % WR) * HALO_WST;
       constexpr int ky = tap / 3, kx = tap - ky * 3;
