@@ -79,6 +79,12 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
   float* const brv = reinterpret_cast<float*>(smem + Cfg::BRVOFF);
 
   DC_STAMP(0);
+#ifdef DC_STAMPS   // workgroup turnover on a CU (tools/dev/ws_turnover.py): wall clock (100 MHz) at start / end and where the workgroup ran
+  if (threadIdx.x == 256) {
+    DC_STAMP_VAL(3, __builtin_amdgcn_s_memrealtime());
+    DC_STAMP_VAL(4, (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32));   // HW_ID, XCC_ID
+  }
+#endif
   const int abl = DC_WS_ABL();                  // 0 outside diagnostic builds
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -359,6 +365,9 @@ __global__ __launch_bounds__(512, 2) void conv3_ws_kernel(const IgemmArgs a, con
   };
   epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, ng, ng, rowfn, EpiNoPre(), qsfn, HaloLdsBias{brv + wn * 64 + lq * 8});
   DC_STAMP(7);
+#ifdef DC_STAMPS
+  if (threadIdx.x == 0) DC_STAMP_VAL(6, __builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ====================================================================================================================

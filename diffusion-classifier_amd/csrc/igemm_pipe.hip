@@ -333,6 +333,11 @@ int dc_igemm_pipe_shape(const IgemmArgs& a) {
   if (!no_wide && wide_act && a.taps == 1 && (a.tiles_n & 1) == 0 && a.nk >= wide_min_nk &&
       (long long)((a.M + 255) / 256) * (a.tiles_n / 2) >= wide_min_tiles) return 2;
   if (a.nk <= light_nk) return 0;
+  // a grid of 256-row tiles that does not give every CU a workgroup (the fp32 side-path GEMMs: M = work units, e.g. DiT-B/4's adaLN
+  // modulation, 2 x 36 tiles): the 128-row tile, two workgroups per CU — 5.75 -> 3.41 ms per cfg5 step for those 50 launches
+  const char* ct = getenv("DCAMD_PIPE_CHIP_TILES");          // read per call (~0.1 us): the tests pin the 256-row tile on small shapes with 0
+  const long long chip_tiles = ct ? atoll(ct) : 256;
+  if ((long long)((a.M + 255) / 256) * a.tiles_n < chip_tiles) return 0;
   return 1;
 }
 

@@ -44,13 +44,15 @@ def run_igemm(**kw):
 
 
 @pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
-@pytest.mark.parametrize("case", ["plain", "stride2", "upsample", "concat", "maps", "small_n", "ragged_m", "side", "side_maps", "thin"])
-def test_conv3x3(dt, case):
+@pytest.mark.parametrize("case", ["plain", "stride2", "stride2_tile256", "upsample", "concat", "maps", "small_n", "ragged_m", "side", "side_maps", "thin"])
+def test_conv3x3(dt, case, monkeypatch):
     torch.manual_seed(1)
     g = E.bke(dt)
     N, H, W, C0, C1, Cout, stride, up = 3, 8, 8, 2 * g, 0, 128, 1, 0
     tile_n = 128
-    if case == "stride2":
+    if case == "stride2_tile256":           # the 256-row tile of igemm_pipe on a grid that does not fill the chip (the dispatcher would take the 128-row one)
+        monkeypatch.setenv("DCAMD_PIPE_CHIP_TILES", "0")
+    if case.startswith("stride2"):
         stride = 2
     if case == "upsample":
         up = 1
