@@ -103,7 +103,11 @@ __device__ __forceinline__ float gelu_erf_fast_f(float x) {       // same formul
   const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);
   return 0.5f * x * (1.0f + copysignf(r, z));
 }
+#ifdef DC_GEGLU_ABL   // timing-only diagnostic build: the GEGLU epilogue without its erf (results wrong on purpose)
+template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) { return x; }
+#else
 template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) { return sizeof(T) == 2 ? gelu_erf_fast_f(x) : gelu_erf_f(x); }
+#endif
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float k = 0.79788456080286535588f;  // sqrt(2/pi)
   // 0.5 x (1 + tanh u) == x / (1 + exp(-2u)): one exp + one divide instead of ocml tanhf (the DiT fc1 epilogue was
