@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCAMD_LIB") or os.path.join(_HERE, "libdcamd.so")   # DCAMD_LIB: diagnostic builds only
 
-ABI_VERSION = 2      # include/dcamd.h DC_ABI_VERSION
+ABI_VERSION = 3      # include/dcamd.h DC_ABI_VERSION
 DC_F32, DC_BF16, DC_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GELU_TANH = 0, 1, 2, 3
 OP_QSAMPLE, OP_SINUSOID, OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_EPS_MSE = 1, 2, 3, 4, 5, 6, 7
@@ -73,7 +73,7 @@ class EpsMseParams(C.Structure):
 class DdpmStepParams(C.Structure):
     _fields_ = [("z", vp), ("pred", vp), ("noise", vp), ("out", vp),
                 ("n", i32), ("C", i32), ("H", i32), ("W", i32), ("ld", i32), ("patch", i32), ("v_param", i32),
-                ("w", f32), ("alpha_t", f32), ("sigma_t", f32), ("alpha_s", f32), ("c", f32), ("sd", f32)]
+                ("w", f32), ("alpha_t", f32), ("sigma_t", f32), ("alpha_s", f32), ("c", f32), ("sd", f32), ("one_plus_w", f32)]
 
 
 class Op(C.Structure):

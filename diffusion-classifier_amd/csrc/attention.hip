@@ -79,7 +79,7 @@ bool dc_attn_mfma_applicable(int dtype, int L, int d);
 int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s);
 bool dc_attn_wave_applicable(const dc_attention_params* p);  // L <= 64: one wave per (sample, head) pair
 int dc_attn_wave_launch(const dc_attention_params* p, hipStream_t s);
-bool dc_attn_flash_applicable(int dtype, int L, int d);     // long sequences (DiT), online softmax
+bool dc_attn_flash_applicable(const dc_attention_params* p);   // long sequences (DiT), online softmax
 int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s);
 
 extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
@@ -87,15 +87,15 @@ extern "C" int dc_attention(const dc_attention_params* p, dc_stream stream) {
   DC_REQUIRE(p->d == 16 || p->d == 32 || p->d == 64 || p->d == 128, DC_ERR_SHAPE, "dc_attention: head dim %d (16/32/64/128)", p->d);
   DC_REQUIRE(p->n > 0 && p->L > 0 && p->heads > 0, DC_ERR_SHAPE, "dc_attention: n/L/heads");
   DC_REQUIRE(p->ld_qkv >= p->heads * p->d && p->ld_out >= p->heads * p->d, DC_ERR_SHAPE, "dc_attention: ld");
-  static const bool no_mfma = getenv("DCAMD_ATTN_VALU") != nullptr;
+  // the matrix-core kernels keep the running max of the RAW scores and fold the scale into the exponent's FMA: valid for scale > 0 only
+  DC_REQUIRE(p->scale > 0.f, DC_ERR_ARG, "dc_attention: scale must be positive (got %g)", (double)p->scale);
   // L <= 64: one wave per pair (attn_wave_kernel); up to 128: the whole-sequence matrix-core kernel; beyond: the flash kernel, which
   // also wins at 256 tokens (CheXpert 16x16 level, d = 64: 2.37 -> 0.71 ms per step; IPMSA: 13.2 -> 4.8 ms)
-  static const int mfma_maxl = getenv("DCAMD_ATTN_MFMA_MAXL") ? atoi(getenv("DCAMD_ATTN_MFMA_MAXL")) : 128;
-  if (!no_mfma && dc_attn_wave_applicable(p)) return dc_attn_wave_launch(p, reinterpret_cast<hipStream_t>(stream));
-  if (!no_mfma && p->L <= mfma_maxl && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
-  static const bool force_flash = getenv("DCAMD_ATTN_FLASH") != nullptr;
+  constexpr int mfma_maxl = 128;
+  if (dc_attn_wave_applicable(p)) return dc_attn_wave_launch(p, reinterpret_cast<hipStream_t>(stream));
+  if (p->L <= mfma_maxl && dc_attn_mfma_applicable(p->dtype, p->L, p->d)) return dc_attn_mfma_launch(p, reinterpret_cast<hipStream_t>(stream));
   const size_t lds_all = (size_t)2 * p->L * p->d * sizeof(float);
-  if (!no_mfma && (lds_all > 160 * 1024 || force_flash || p->L > mfma_maxl) && dc_attn_flash_applicable(p->dtype, p->L, p->d))
+  if ((lds_all > 160 * 1024 || p->L > mfma_maxl) && dc_attn_flash_applicable(p))
     return dc_attn_flash_launch(p, reinterpret_cast<hipStream_t>(stream));
   // fp32 (the parity path) and shapes the matrix-core kernels do not take: exact fp32 kernel; K / V stay whole in LDS when they
   // fit 160 KiB (one block: the order of operations of the UNet parity path is unchanged), else stream in 64 KiB blocks

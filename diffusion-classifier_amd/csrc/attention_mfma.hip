@@ -132,8 +132,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMArgs a) {
 // (sample, head) pairs per workgroup.  L == 64 (8x8 tokens), d <= 64: four pairs, one wave each, instead of four waves on
 // one pair — the four heads' 128-byte pieces of a qkv row are then fetched together (2.47 -> 2.67 TB/s on cfg2's blocks).
 static int attn_pairs_per_wg(int L, int d) {
-  static const int g64 = getenv("DCAMD_ATTN_G64") ? atoi(getenv("DCAMD_ATTN_G64")) : 4;
-  if (L == 64 && d <= 64 && (g64 == 2 || g64 == 4)) return g64;
+  if (L == 64 && d <= 64) return 4;
   return L >= 64 ? 1 : (L == 32 ? 2 : (L == 16 ? 4 : 0));
 }
 
@@ -173,143 +172,11 @@ int dc_attn_mfma_launch(const dc_attention_params* p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Long sequences (DiT: 1024 / 4096 tokens): flash-style forward.  A 4-wave workgroup owns 128 queries
-// of one (sample, head) — 32 per wave, two 16-query MFMA tiles — and walks the keys in blocks of 128:
-// K block [128][d] and V^T block [d][128] are staged in LDS once per block and shared by the four
-// waves; scores, running max / sum and the output accumulators stay in registers (online softmax,
-// fp32); P goes through a per-wave LDS strip to become the A operand of P.V.
+// Long sequences (DiT: 1024 / 4096 tokens; 256 tokens of the CheXpert / IPMSA UNets)
 struct FlashArgs {
   const void* q; const void* k; const void* v; void* out;
   int n, L, heads, d, ld_qkv, ld_out; float scale;
 };
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
-  constexpr int KB = 128;                                     // keys per block
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lr = lane & 15, lq = lane >> 4;
-  const int L = a.L, d = a.d;
-  const int KS = d + 8, VS = KB + 8, PS = KB + 8;
-  T* Ks = reinterpret_cast<T*>(smem);
-  T* Vt = Ks + KB * KS;
-  T* Pw = Vt + d * VS + wave * 32 * PS;
-  const int qblocks = (L + 127) / 128;
-  int b = blockIdx.x;
-  const int qb = b % qblocks; b /= qblocks;
-  const int h = b % a.heads, n = b / a.heads;
-  const T* qg = reinterpret_cast<const T*>(a.q) + (size_t)n * L * a.ld_qkv + h * d;
-  const T* kg = reinterpret_cast<const T*>(a.k) + (size_t)n * L * a.ld_qkv + h * d;
-  const T* vg = reinterpret_cast<const T*>(a.v) + (size_t)n * L * a.ld_qkv + h * d;
-  const int kblocks = d / 32, dtiles = d / 16;
-  const int q0 = qb * 128 + wave * 32;                        // first query of this wave
-
-  chunk16 qf[2][4];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-      if (kb < kblocks) {
-        const int qi = q0 + qt * 16 + lr;
-        qf[qt][kb] = *reinterpret_cast<const chunk16*>(qg + (size_t)(qi < L ? qi : L - 1) * a.ld_qkv + kb * 32 + lq * 8);
-      }
-  f32x4 O[2][8];
-  float m[2][4], l[2][4];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) O[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m[qt][r] = -INFINITY; l[qt][r] = 0.f; }
-  }
-  const int cpr = d / 8;
-  for (int k0 = 0; k0 < L; k0 += KB) {
-    __syncthreads();                                          // previous block fully consumed
-    for (int idx = t; idx < KB * cpr; idx += 256) {
-      const int r = idx / cpr, c = idx - r * cpr;
-      const int key = k0 + r;
-      chunk16 kc = {0u, 0u, 0u, 0u}, vc = {0u, 0u, 0u, 0u};
-      if (key < L) {
-        kc = *reinterpret_cast<const chunk16*>(kg + (size_t)key * a.ld_qkv + c * 8);
-        vc = *reinterpret_cast<const chunk16*>(vg + (size_t)key * a.ld_qkv + c * 8);
-      }
-      *reinterpret_cast<chunk16*>(Ks + r * KS + c * 8) = kc;
-      const typename Elem<T>::vec ve = __builtin_bit_cast(typename Elem<T>::vec, vc);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VS + r] = ve[e];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      f32x4 S[8];
-      float mx[4] = {m[qt][0], m[qt][1], m[qt][2], m[qt][3]};
-#pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-          if (kb < kblocks) {
-            const chunk16 kf = *reinterpret_cast<const chunk16*>(Ks + (kt * 16 + lr) * KS + kb * 32 + lq * 8);
-            acc = Mma<T>::run(qf[qt][kb], kf, acc);
-          }
-        const bool kvalid = k0 + kt * 16 + lr < L;             // keys past L never win the max nor add to the sum
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[r] = kvalid ? acc[r] * a.scale : -INFINITY; mx[r] = fmaxf(mx[r], acc[r]); }
-        S[kt] = acc;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
-      float corr[4], ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { corr[r] = expf(m[qt][r] - mx[r]); m[qt][r] = mx[r]; }
-#pragma unroll
-      for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = expf(S[kt][r] - mx[r]);
-          ps[r] += p;
-          Pw[(qt * 16 + lq * 4 + r) * PS + kt * 16 + lr] = Elem<T>::from_f(p);
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ps[r] += __shfl_xor(ps[r], o, 64);
-        l[qt][r] = l[qt][r] * corr[r] + ps[r];
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt)
-        if (dt < dtiles) {
-          f32x4 acc = O[qt][dt];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] *= corr[r];
-#pragma unroll
-          for (int kb2 = 0; kb2 < KB / 32; ++kb2) {
-            const chunk16 pf = *reinterpret_cast<const chunk16*>(Pw + (qt * 16 + lr) * PS + kb2 * 32 + lq * 8);
-            const chunk16 vf = *reinterpret_cast<const chunk16*>(Vt + (dt * 16 + lr) * VS + kb2 * 32 + lq * 8);
-            acc = Mma<T>::run(pf, vf, acc);
-          }
-          O[qt][dt] = acc;
-        }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-      if (dt < dtiles) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = q0 + qt * 16 + lq * 4 + r;
-          if (qi < L)
-            reinterpret_cast<T*>(a.out)[((size_t)n * L + qi) * a.ld_out + h * d + dt * 16 + lr] = Elem<T>::from_f(O[qt][dt][r] / l[qt][r]);
-        }
-      }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Flash forward, transposed-score form (head dims 32 / 64 / 128): no transposed V image, no LDS round trip for P.
@@ -321,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
 //                   (the k order inside an MFMA is free as long as A agrees), and the matching A operand (4 + 4
 //                   consecutive keys of one d column) is two ds_read_b64_tr_b16 of the ROW-MAJOR V image
 // K / V blocks of 128 / 64 / 32 keys (d = 32 / 64 / 128) are register-staged (global loads of block i+1 issued before the MFMAs of block i, written to
-// the other LDS buffer after them), one barrier per block.  The first version (attn_flash_kernel above: transposed V
-// staged with 2-byte LDS writes, P through LDS, no prefetch) ran DiT-B/4 attention at 0.2 PF.
+// the other LDS buffer after them), one barrier per block.  (The first version — transposed V staged with 2-byte LDS writes, P through
+// LDS, no prefetch — ran DiT-B/4 attention at 0.2 PF and was removed in round 4.)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
@@ -688,8 +555,7 @@ static int launch_attn_wave(const FlashArgs& a, hipStream_t s) {
 
 // one wave per pair: 16-bit, L <= 64, d in {32, 64, 128}, 8-byte aligned output rows
 bool dc_attn_wave_applicable(const dc_attention_params* p) {
-  static const bool off = getenv("DCAMD_ATTN_NO_WAVE") != nullptr;
-  if (off || p->dtype == DC_F32 || p->L > 64 || !(p->d == 32 || p->d == 64 || p->d == 128)) return false;
+  if (p->dtype == DC_F32 || p->L > 64 || !(p->d == 32 || p->d == 64 || p->d == 128)) return false;
   if ((((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v) & 15) || (p->ld_qkv % 8)) return false;
   return p->ld_out % 4 == 0 && (((uintptr_t)p->out) & 7) == 0;
 }
@@ -706,31 +572,17 @@ int dc_attn_wave_launch(const dc_attention_params* p, hipStream_t s) {
 #undef DC_AW
 }
 
-bool dc_attn_flash_applicable(int dtype, int L, int d) { return dtype != DC_F32 && d % 32 == 0 && d <= 128 && L >= 1; }
+bool dc_attn_flash_applicable(const dc_attention_params* p) {
+  return p->dtype != DC_F32 && (p->d == 32 || p->d == 64 || p->d == 128) && p->L >= 1 && p->ld_out % 4 == 0 && (((uintptr_t)p->out) & 7) == 0 &&
+         ((((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v) & 15) == 0) && p->ld_qkv % 8 == 0;
+}
 
 int dc_attn_flash_launch(const dc_attention_params* p, hipStream_t s) {
   FlashArgs a{p->q, p->k, p->v, p->out, p->n, p->L, p->heads, p->d, p->ld_qkv, p->ld_out, p->scale};
-  if ((((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v) & 15) || (p->ld_qkv % 8)) {
-    dc_set_error("dc_attention: q/k/v must be 16-byte aligned with ld %% 8 == 0");
-    return DC_ERR_ALIGN;
-  }
-  const size_t lds = ((size_t)128 * (p->d + 8) + (size_t)p->d * 136 + (size_t)4 * 32 * 136) * 2;
   const long long nb = (long long)p->n * p->heads * ((p->L + 127) / 128);
   if (nb >= (1LL << 31)) { dc_set_error("dc_attention: grid too large"); return DC_ERR_SHAPE; }
-  static const bool old_flash = getenv("DCAMD_ATTN_FLASH_V1") != nullptr;
-  if (!old_flash && (p->d == 32 || p->d == 64 || p->d == 128) && p->ld_out % 4 == 0 && (((uintptr_t)p->out) & 7) == 0) {
-    const bool bf = p->dtype == DC_BF16;
-    if (p->d == 32) return bf ? launch_flash_t<__bf16, 32>(a, nb, s) : launch_flash_t<_Float16, 32>(a, nb, s);
-    if (p->d == 64) return bf ? launch_flash_t<__bf16, 64>(a, nb, s) : launch_flash_t<_Float16, 64>(a, nb, s);
-    return bf ? launch_flash_t<__bf16, 128>(a, nb, s) : launch_flash_t<_Float16, 128>(a, nb, s);
-  }
-  static bool done_b = false, done_h = false;
-  if (p->dtype == DC_BF16) {
-    if (!done_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_flash_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_b = true; }
-    hipLaunchKernelGGL((attn_flash_kernel<__bf16>), dim3((unsigned)nb), dim3(256), lds, s, a);
-  } else {
-    if (!done_h) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_flash_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done_h = true; }
-    hipLaunchKernelGGL((attn_flash_kernel<_Float16>), dim3((unsigned)nb), dim3(256), lds, s, a);
-  }
-  return dc_check_launch("dc_attention(flash)");
+  const bool bf = p->dtype == DC_BF16;
+  if (p->d == 32) return bf ? launch_flash_t<__bf16, 32>(a, nb, s) : launch_flash_t<_Float16, 32>(a, nb, s);
+  if (p->d == 64) return bf ? launch_flash_t<__bf16, 64>(a, nb, s) : launch_flash_t<_Float16, 64>(a, nb, s);
+  return bf ? launch_flash_t<__bf16, 128>(a, nb, s) : launch_flash_t<_Float16, 128>(a, nb, s);
 }

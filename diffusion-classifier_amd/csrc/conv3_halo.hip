@@ -14,7 +14,7 @@
 //           into reading fragments and issuing MFMAs at the same moments (the 8-wave form measured
 //           ~2,000 cycles per tap against 1,024 of MFMA work).  [default]
 //   NW = 8: 512-pixel patch, 8 waves as 4(M) x 2(N), 147 KiB, one workgroup per CU: half the weight
-//           traffic per pixel (DCAMD_HALO_NW=8 selects it).
+//           traffic per pixel (images of 8x8 and below).
 //   Wave tile 128 pixels x 64 couts (32 MFMA 16x16x32 per tap) in both.
 //
 //   X halo: double-buffered per channel chunk (the next chunk's halo is fetched during the current
@@ -45,7 +45,6 @@ static __device__ chunk16 g_zero_page[16];   // per translation unit (no device-
 #include "conv3_halo.h"
 DC_CLOCK_DECL(conv3_halo)
 
-// GN: fused GroupNorm(+SiLU) prologue compiled in (opt-in variant; the plain kernel carries none of its code)
 // NTAP: 9 = the 3x3 conv.  4 = one PHASE of "nearest-2x upsample, then 3x3 conv" (dc_igemm_params.up4): output pixel
 // (2y+pa, 2x+pb) only sees the 2x2 source pixels (y+pa-1+dy, x+pb-1+dx), with the 3x3 taps that fall on the same source
 // pixel summed when the weights are packed — 4 taps instead of 9, the same halo of the LOW-resolution image; the four
@@ -54,7 +53,7 @@ DC_CLOCK_DECL(conv3_halo)
 // patch); 2 (MOS) = mosaic patches of images below 8x8 (HaloGeom::mos; a wave's pixels then span eight samples, so the epilogue
 // fetches the per-sample row vector per pixel fragment).  Separate instantiations, so that no form carries another's registers
 // (the kernel sits at the SGPR / VGPR limits of two waves per SIMD).
-// STG (8 waves, no fused GroupNorm): the tap loop in HALF-steps with the two wave groups (waves 0-3 / 4-7 = the two waves of every
+// STG (8 waves): the tap loop in HALF-steps with the two wave groups (waves 0-3 / 4-7 = the two waves of every
 // SIMD) running ONE BARRIER APART — the schedule of igemm_wide.hip applied to the halo loop.  A step is
 //   b ; R_a { issue W(s+PD) ; read the 4 W fragments and pixel fragments 0-3 } ; b ; M_a { 16 MFMAs } ;
 //   b ; R_b { tap 0: issue X(cc+1) ; read pixel fragments 4-7 ; wait for my piece of W(s+1) } ; b ; M_b { 16 MFMAs }
@@ -68,9 +67,9 @@ DC_CLOCK_DECL(conv3_halo)
 //        instance 4s; the earliest re-stage (A, R_a(s)) comes after instance 4s+1.  X(cc+1) goes into X(cc-1)'s buffer: last read by
 //        B in R_b of the previous chunk's last step, retired before B arrives at the instance A's R_b of tap 0 waits behind.
 // One accumulator gets one MFMA per step in both loops: results are bit-identical.
-template <typename T, int NW, bool GN, int NTAP = 9, int MODE = 0, bool STG = false>
+template <typename T, int NW, int NTAP = 9, int MODE = 0, bool STG = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
-  static_assert(!STG || (NW == 8 && !GN), "staggered loop: the 8-wave kernel without the fused GroupNorm");
+  static_assert(!STG || NW == 8, "staggered loop: the 8-wave kernel");
   constexpr bool XB = MODE == 1, MOS = MODE == 2;
   using Cfg = HaloCfg<NW>;
   constexpr int EPC = Elem<T>::EPC;
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // GroupNorm slot, unused here) while the piece offsets are being formed — the epilogue then reads them at LDS latency instead of
   // paying a global-load round trip (~2.5 k of a ~19 k-cycle epilogue by s_memtime stamps) in front of its first use.
   float* const brv = reinterpret_cast<float*>(smem + Cfg::GNOFF);
-  constexpr bool STAGE_BRV = XB && !GN;
+  constexpr bool STAGE_BRV = XB;
   if (STAGE_BRV && t < 128) {
     const int c = tile_n * 128 + t;
     float v = 0.f;
@@ -192,40 +191,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     }
   };
   if constexpr (XROW) retarget(0);
-
-  // ---- fused GroupNorm(+SiLU) prologue: y = act(x*scale[n][c] + shift[n][c]) applied IN PLACE on the landed halo ----
-  // (one sample per workgroup; every lane transforms exactly the 16-byte chunks it fetched, and skips padding rows,
-  //  which must stay 0 because the reference pads the NORMALISED tensor)
-  constexpr bool gn = GN;
-  float* const gnp = reinterpret_cast<float*>(smem + Cfg::GNOFF);
-  if (gn) {
-    const int n0 = ng << g.lni;
-    if (n0 < g.n_img)
-      for (int c = t; c < Ctot; c += NT) {
-        gnp[c] = a.gn_scale[(size_t)n0 * Ctot + c];
-        gnp[Ctot + c] = a.gn_shift[(size_t)n0 * Ctot + c];
-      }
-    __syncthreads();
-  }
-  auto xform = [&](int ccx, int i) {
-    if (i < g.nxl && pp[i] >= 0 && tbl[4 * ((pp[i] & PKMASK) >> 20)] >= 0) {
-      chunk16* p = reinterpret_cast<chunk16*>(smem + (ccx & 1) * Cfg::XBUF + (i * NT + t) * 16);
-      float f[EPC];
-      chunk_to_f<T>(*p, f);
-      const float* sc = gnp + ccx * BKE + (xlx ^ (sw_of(pp[i]) << 1)) * EPC;
-      const float* sh = sc + Ctot;
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        float v = f[e] * sc[e] + sh[e];
-        if (a.gn_silu) {
-          if (sizeof(T) == 4) v = silu_f(v);                       // f32 parity path: accurate exp / divide
-          else v = v * __frcp_rn(1.0f + __expf(-v));               // 16-bit path: v_exp + v_rcp (result is rounded to 16 bit anyway)
-        }
-        f[e] = v;
-      }
-      *p = f_to_chunk<T>(f);
-    }
-  };
 
   // ---- XB: buffer descriptors (wave-uniform by construction: kernel arguments and blockIdx only).  All four share the range
   // (2 GiB - 1: every real offset is below it by the host's checks) and the format word, so only the bases differ.
@@ -543,11 +508,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   issue_x(0);
 #pragma unroll
   for (int i = 0; i < PD; ++i) issue_w(0, i, i);     // a chunk has NTAP taps >= PD
-  if (gn) {                                          // chunk 0: transform before the first tap
-    hwait_vmcnt<PD * WLD>();                         // own X(0) loads have landed (the W groups may stay in flight)
-#pragma unroll
-    for (int i = 0; i < NXL; ++i) xform(0, i);
-  }
   constexpr int FLYL = (PD - 1) * WLD;               // W(s+1) .. W(s+PD-1)
   DC_CLOCK(0);
   for (int cc = 0; cc < nchunks; ++cc) {
@@ -568,7 +528,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
         constexpr int left = NTAP - 1 - tap;        // W groups behind this one
         hwait_vmcnt<(left < PD - 1 ? left : PD - 1) * WLD>();
       }
-      if (gn && tap == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my in-place writes of this chunk are in LDS
       __builtin_amdgcn_s_barrier();
       constexpr int t2 = tap + PD;                    // the W group to issue now: s + PD
       if (t2 < NTAP) issue_w(cc, t2, (s0 + t2) % WR);
@@ -580,9 +539,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       constexpr int ky = UP4 ? (tap >> 1) : tap / 3, kx = UP4 ? (tap & 1) : tap - ky * 3;
       const int tapoff = ((ky + pa) * g.hw + kx + pb) * 64;       // pa = pb = 0 for the 3x3 conv
       mma_tap(Wst, Xb, tapoff, IC<kx>{});
-      // X(cc+1) was issued at tap 0 and this lane's own pieces were waited for at tap PD+1: from then on transform
-      // one piece per tap, behind this tap's MFMAs (other waves read the buffer only after the next chunk's barrier)
-      if (gn && tap > PD && has_next) xform(cc + 1, tap > PD ? tap - PD - 1 : 0);
     };
     step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
     if constexpr (NTAP == 9) { step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{}); step(IC<8>{}); }
@@ -595,7 +551,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   // and W2(0 .. PD-1) were issued inside the last 3x3 chunk; a step needs a fresh halo chunk per 32 MFMAs, so from the second
   // step on the loads of the previous step are simply drained (vmcnt 0): ~2 k exposed cycles per step, against the whole
   // shortcut GEMM launch and the residual round trip this replaces. ----
-  if (!gn) {
+  {
     const int NSm = nchunks * NTAP;
     for (int e = 0; e < nx; ++e) {
       if (e == 0 && nx >= PD) hwait_vmcnt<FLY>();      // W2(1 .. PD-1) may stay in flight; X2(0) landed long ago
@@ -843,33 +799,19 @@ bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype) {
   return true;
 }
 
-// fused GroupNorm prologue: one sample per workgroup, affine table fits its LDS slot, one halo piece per remaining tap
-bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype) {
-  if (!dc_conv3_halo_applicable(a, dtype) || a.upsample) return false;
-  static const int nw_env = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
-  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : (nw_env == 8 ? 8 : 4);
-  const int pix = nw * 64, nt = nw * 64, pd = (nw == 4 ? 3 : 4) - 1;
-  const int tw = a.Win < 32 ? a.Win : 32;
-  int th = pix / tw; if (th > a.Hin) th = a.Hin;
-  if (pix / (tw * th) != 1) return false;
-  const int hr = (th + 2) * (tw + 2), nxl = (hr * 4 + nt - 1) / nt;
-  return a.C0 + a.C1 <= 512 && nxl <= 8 - pd;
-}
-
 template <typename T, int NW>
 static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 = false) {
   using Cfg = HaloCfg<NW>;
-  static bool attr_done_v[3] = {false, false, false};
-  bool& attr_done = attr_done_v[up4 ? 2 : (a0.gn_scale ? 1 : 0)];
-  void (*kern)(const IgemmArgs, const HaloGeom) = up4 ? conv3_halo_kernel<T, NW, false, 4>
-                                                  : (a0.gn_scale ? conv3_halo_kernel<T, NW, true> : conv3_halo_kernel<T, NW, false>);
+  static bool attr_done_v[2] = {false, false};
+  bool& attr_done = attr_done_v[up4 ? 1 : 0];
+  void (*kern)(const IgemmArgs, const HaloGeom) = up4 ? conv3_halo_kernel<T, NW, 4> : conv3_halo_kernel<T, NW>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 9, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, 9, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if constexpr (NW == 8) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, false, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, 9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<T, NW, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     }
     attr_done = true;
   }
@@ -895,11 +837,10 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   }
   g.inv_hp = g.hp ? 1.0f / (float)g.hp : 0.f; g.inv_hw = 1.0f / (float)g.hw;
   g.sws = (g.ltw < 4 ? g.ltw : 4) - 2;     // tw >= 16: 2, 8: 1, 4 (mosaic): 0
-  static const bool no_xbuf = getenv("DCAMD_HALO_NO_XBUF") != nullptr;
   {
     const long long hws = (long long)(a.upsample ? (g.H >> 1) * (g.W >> 1) : g.H * g.W);
     const long long ldmax = a.ld0 > a.ld1 ? (a.ld0 > a.ld2 ? a.ld0 : a.ld2) : (a.ld1 > a.ld2 ? a.ld1 : a.ld2);
-    g.xbuf = (!no_xbuf && ni == 1 && !g.mos && !a.gn_scale && hws * ldmax * (long long)sizeof(T) < (1LL << 31) &&
+    g.xbuf = (ni == 1 && !g.mos && hws * ldmax * (long long)sizeof(T) < (1LL << 31) &&
               (long long)a.tiles_n * 128 * a.Ktot * (long long)sizeof(T) < (1LL << 31)) ? 1 : 0;
   }
   if ((long long)a.tiles_n * 128 * a.Ktot >= (1LL << 31)) { dc_set_error("conv3_halo: weight matrix of %d x %d too large", a.tiles_n * 128, a.Ktot); return DC_ERR_SHAPE; }
@@ -908,18 +849,18 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   a.tiles_m = ((n_img + ni - 1) / ni) * g.tiles_x * g.tiles_y;
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
-  if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 1> : conv3_halo_kernel<T, NW, false, 9, 1>;
+  if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, 4, 1> : conv3_halo_kernel<T, NW, 9, 1>;
   if constexpr (NW == 8) {
-    if (g.mos) kern = up4 ? conv3_halo_kernel<T, NW, false, 4, 2> : conv3_halo_kernel<T, NW, false, 9, 2>;
+    if (g.mos) kern = up4 ? conv3_halo_kernel<T, NW, 4, 2> : conv3_halo_kernel<T, NW, 9, 2>;
     // staggered wave groups (STG) unless DCAMD_HALO_NO_STAG (read per call: A/B runs in one process)
     // (the four-tap upsample form stays on the lock-step loop: its whole next halo would ride in one MFMA block — measured slower)
-    if (!up4 && !a0.gn_scale && !getenv("DCAMD_HALO_NO_STAG") && (long long)a.tiles_n * 128 * a.Ktot * (long long)sizeof(T) < (1LL << 31)) {
+    if (!up4 && !getenv("DCAMD_HALO_NO_STAG") && (long long)a.tiles_n * 128 * a.Ktot * (long long)sizeof(T) < (1LL << 31)) {
       const int mode = g.mos ? 2 : (g.xbuf ? 1 : 0);
       static bool stg_attr[3] = {false, false, false};
       switch (mode) {
-        case 0: kern = conv3_halo_kernel<T, NW, false, 9, 0, true>; break;
-        case 1: kern = conv3_halo_kernel<T, NW, false, 9, 1, true>; break;
-        default: kern = conv3_halo_kernel<T, NW, false, 9, 2, true>; break;
+        case 0: kern = conv3_halo_kernel<T, NW, 9, 0, true>; break;
+        case 1: kern = conv3_halo_kernel<T, NW, 9, 1, true>; break;
+        default: kern = conv3_halo_kernel<T, NW, 9, 2, true>; break;
       }
       if (!stg_attr[mode]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -946,8 +887,7 @@ int dc_conv3_up4_launch(const IgemmArgs& a0, int dtype, int n_img, hipStream_t s
   a.Ktot = 4 * (a.C0 + a.C1);
   a.tiles_n = 4 * a0.tiles_n;                                    // phase-major N tiles
   a.n_fast = 0;
-  static const int nw_env = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
-  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : nw_env;
+  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : 4;
   if (nw == 8) {
     if (dtype == DC_BF16) return launch_halo<__bf16, 8>(a, n_img, s, true);
     if (dtype == DC_F16) return launch_halo<_Float16, 8>(a, n_img, s, true);
@@ -959,10 +899,9 @@ int dc_conv3_up4_launch(const IgemmArgs& a0, int dtype, int n_img, hipStream_t s
 }
 
 int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s) {
-  static const int nw_env = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
   // 8x8 images: deep layers (Cout >= 256) are weight-traffic bound, so they take the 512-pixel patch (half the
   // weight bytes per pixel); the 256-pixel patch would also need 4 x 100 halo rows = 7 loads per lane
-  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : nw_env;
+  const int nw = (a.Hin <= 8 || a.Win <= 8) ? 8 : 4;
   if (nw == 8) {
     if (dtype == DC_BF16) return launch_halo<__bf16, 8>(a, n_img, s);
     if (dtype == DC_F16) return launch_halo<_Float16, 8>(a, n_img, s);

@@ -232,11 +232,12 @@ extern "C" int dc_eps_mse(const dc_eps_mse_params* p, dc_stream stream) {
 // One ancestral DDPM step with classifier-free guidance (reference diffusion_classifier.py:175-208 ddpm_sampler_step and the
 // update at :262-266), fused: the guidance mix, the x-prediction, the clip, the posterior mean and the noise add are one pass over
 // the image instead of ~14 elementwise torch launches.  Same operation ORDER as the reference's torch expressions and no
-// contraction, so every element equals the torch evaluation of the same fp32 scalars bit for bit.
+// contraction, so every element equals the torch evaluation of the same fp32 scalars bit for bit — (1 + w) included: the caller
+// passes one_plus_w = float(1.0 + w), the Python double rounded ONCE as torch does (1.f + (float)w can differ by an ulp).
 struct DdpmArgs {
   const float* z; const float* pred; const float* noise; float* out;
   int C, HW, W, ld, patch, v_param, n;
-  float w, alpha_t, sigma_t, alpha_s, c, sd;
+  float w, one_plus_w, alpha_t, sigma_t, alpha_s, c, sd;
 };
 
 __global__ __launch_bounds__(256) void ddpm_step_kernel(const DdpmArgs a) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const DdpmArgs a) {
     }
     const float pc = a.pred[(size_t)(2 * b) * rows * a.ld + pi], pu = a.pred[(size_t)(2 * b + 1) * rows * a.ld + pi];
     const float zt = a.z[i];
-    const float pr = (1.f + a.w) * pc - a.w * pu;                               // pred = (1 + w) * pred - w * u_pred
+    const float pr = a.one_plus_w * pc - a.w * pu;                              // pred = (1 + w) * pred - w * u_pred
     float xp = a.v_param ? a.alpha_t * zt - a.sigma_t * pr : (zt - a.sigma_t * pr) / a.alpha_t;
     xp = fminf(fmaxf(xp, -1.f), 1.f);                                            // clip
     const float mu = a.alpha_s * (zt * (1.f - a.c) / a.alpha_t + a.c * xp);
@@ -270,7 +271,7 @@ extern "C" int dc_ddpm_step(const dc_ddpm_step_params* p, dc_stream stream) {
   DC_REQUIRE(p->n > 0 && p->C > 0 && p->H > 0 && p->W > 0 && p->ld >= p->C * pp * pp, DC_ERR_SHAPE, "dc_ddpm_step: extents");
   DC_REQUIRE(p->H % pp == 0 && p->W % pp == 0, DC_ERR_SHAPE, "dc_ddpm_step: patch=%d does not tile %dx%d", pp, p->H, p->W);
   DdpmArgs a{p->z, p->pred, p->noise, p->out, p->C, p->H * p->W, p->W, p->ld, pp, p->v_param, p->n,
-             p->w, p->alpha_t, p->sigma_t, p->alpha_s, p->c, p->sd};
+             p->w, p->one_plus_w, p->alpha_t, p->sigma_t, p->alpha_s, p->c, p->sd};
   const size_t total = (size_t)p->n * p->C * p->H * p->W;
   const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);

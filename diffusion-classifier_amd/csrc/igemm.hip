@@ -271,21 +271,17 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   const int bn = p->tile_n;
   a.tiles_m = (a.M + 127) / 128;
   a.tiles_n = dc_igemm_cout_pad(p->Cout, bn) / bn;
-  static const bool no_nfast = getenv("DCAMD_NO_NFAST") != nullptr;
   {
     // N fastest when the whole weight matrix can stay in an XCD's L2 next to the activation stream (<= 2 MiB), and for 1-tap GEMMs
     // up to DCAMD_NFAST_GEMM_BYTES (default 16 MiB): there the activation panel of an M tile (rows x K) is the big operand — with
     // M fastest it is re-fetched from HBM once per N panel (DiT-B/4 qkv: 9 x 786 MB per launch, the GEMM ran HBM-bound), with N
     // fastest the N tiles of an M tile run side by side on one XCD and share it in L2, while the weights come back from L2 / MALL
-    const char* e = getenv("DCAMD_NFAST_GEMM_BYTES");        // read per call: tools/bench_wide_ab.py --order alternates it in one process
-    const long long gemm_cap = e ? atoll(e) : (16LL << 20);
+    constexpr long long gemm_cap = 16LL << 20;
     const long long wbytes = (long long)dc_igemm_cout_pad(p->Cout, bn) * a.Ktot * dc_dtype_size(p->dtype);
-    a.n_fast = (!no_nfast && a.tiles_n > 1 && (wbytes <= (2 << 20) || (p->taps == 1 && wbytes <= gemm_cap))) ? 1 : 0;
+    a.n_fast = (a.tiles_n > 1 && (wbytes <= (2 << 20) || (p->taps == 1 && wbytes <= gemm_cap))) ? 1 : 0;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // tile_n 128: the LDS-DMA pipelined 256x128 kernel (igemm_pipe.hip).  DCAMD_IGEMM_V1=1 selects the
-  // register-staged 128x128 kernel instead (A/B measurements; same results bit for bit).
-  static const bool env_v1 = getenv("DCAMD_IGEMM_V1") != nullptr;
+  // tile_n 128: the LDS-DMA kernels (igemm_pipe.hip, igemm_wide.hip, igemm_xreg.hip, conv3_*.hip).
   // the LDS-DMA kernels finish with the lane-resident epilogue (igemm_epilogue.h): whole 16-byte runs of 8 channels in
   // and out.  Anything else (channel counts / leading dimensions that are not multiples of 8, unaligned side
   // operands) takes the register-staged kernel, whose element-wise epilogue handles every case.
@@ -295,9 +291,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
                            (!p->rowvec || (((uintptr_t)p->rowvec & 15) == 0 && p->rowvec_ld % 4 == 0)) &&
                            (!p->gate || (((uintptr_t)p->gate & 15) == 0 && p->gate_ld % 4 == 0 && p->act == DC_ACT_NONE)) &&
                            (!p->residual || p->res_dtype == p->dtype) && (p->out_dtype == p->dtype || p->out_dtype == DC_F32);
-  const bool use_v1 = env_v1 || !lane_epi_ok;
+  const bool use_v1 = !lane_epi_ok;
   static const bool no_halo = getenv("DCAMD_NO_HALO") != nullptr;
-  static const int halo_nw = getenv("DCAMD_HALO_NW") ? atoi(getenv("DCAMD_HALO_NW")) : 4;
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
   const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
   // four-phase upsample conv (W in the phase-summed form): the caller opted in, so anything else is an error
@@ -306,8 +301,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
                           (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0 &&
                                          (a.Hin >> 1) >= 8 && (a.Win >> 1) >= 8));      // no quad statistics from mosaic (< 8x8) patches
     // sources smaller than 8x8 (4x4 -> 8x8): the same four phases on the tap-gather kernel (no quad statistics there)
-    static const bool no_pipe_up4 = getenv("DCAMD_NO_PIPE_UP4") != nullptr;
-    const bool up4_pipe = !up4_halo && !no_pipe_up4 && bn == 128 && !use_v1 && !a.src1 && !a.qstats && p->taps == 9 && p->stride == 1 &&
+    const bool up4_pipe = !up4_halo && bn == 128 && !use_v1 && !a.src1 && !a.qstats && p->taps == 9 && p->stride == 1 &&
                           p->upsample && p->act == DC_ACT_NONE && !p->gate && !p->residual && !a.gn_scale && !a.src2 &&
                           p->Hin >= 4 && p->Win >= 4 && p->Hin % 2 == 0 && p->Win % 2 == 0 && (p->Hin < 16 || p->Win < 16);
     if (!up4_halo && !up4_pipe) {
@@ -317,7 +311,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     }
     if (variant) {
       static thread_local char name4[64];
-      if (up4_halo) snprintf(name4, sizeof(name4), "conv3_up4<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 16 || a.Win <= 16) ? 8 : 4);
+      if (up4_halo) snprintf(name4, sizeof(name4), "conv3_up4<%s,%dw>", dn, (a.Hin <= 16 || a.Win <= 16) ? 8 : 4);
       else snprintf(name4, sizeof(name4), "igemm_pipe_up4<%s,256x128,3st>", dn);
       *variant = name4;
       return DC_OK;
@@ -328,7 +322,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   // wave-specialised halo conv: takes the fused GroupNorm prologue (also together with the 1x1 side source / a residual); DCAMD_WS_PLAIN
   // routes the plain one-image-per-patch convs there too (A/B of the structure alone)
   static const bool ws_plain = getenv("DCAMD_WS_PLAIN") != nullptr;
-  const bool ws_ok = halo_ok && !env_v1 && dc_conv3_ws_ok(a, p->dtype) && !dc_conv3_thin_applicable(a, p->dtype);
+  const bool ws_ok = halo_ok && dc_conv3_ws_ok(a, p->dtype) && !dc_conv3_thin_applicable(a, p->dtype);
   const bool use_ws = ws_ok && (a.gn_scale || ws_plain);
   if (a.src2) {
     const int bke64 = 64 / dc_dtype_size(p->dtype);
@@ -340,14 +334,14 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
       return DC_ERR_UNSUPPORTED;
     }
   }
-  const bool thin_gn = a.gn_scale && !env_v1 && dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;   // conv_out: normalised in the halo
-  if (a.gn_scale && !thin_gn && !ws_ok && !(halo_ok && dc_conv3_halo_gn_ok(a, p->dtype))) {
+  const bool thin_gn = a.gn_scale && dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;   // conv_out: normalised in the halo
+  if (a.gn_scale && !thin_gn && !ws_ok) {
     if (variant) { *variant = "gn-not-fusable"; return DC_ERR_UNSUPPORTED; }
     dc_set_error("dc_igemm: gn_scale/gn_shift given but this problem cannot take the fused GroupNorm prologue (see dc_igemm_gn_fusable)");
     return DC_ERR_UNSUPPORTED;
   }
   if (a.qstats) {
-    const bool thin_q = !env_v1 && dc_conv3_thin_applicable(a, p->dtype);
+    const bool thin_q = dc_conv3_thin_applicable(a, p->dtype);
     const bool qs_ok = halo_ok && !thin_q && p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0 &&
                        a.Hin >= 8 && a.Win >= 8;          // mosaic patches (images below 8x8) emit none: a wave's half holds four images
     if (!qs_ok) {
@@ -365,18 +359,18 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     return DC_ERR_UNSUPPORTED;
   }
   const bool use_xreg = bn == 128 && dc_igemm_xreg_applicable(a, p->dtype) && (p->act == DC_ACT_GEGLU || a.ln_eps > 0.f || dc_igemm_pipe_shape(a) != 2);
-  const bool thin = !env_v1 && dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;
+  const bool thin = dc_conv3_thin_applicable(a, p->dtype) && ((uintptr_t)p->out & 3) == 0;
   if (variant) {
     static thread_local char name[64];
     if (thin) { snprintf(name, sizeof(name), "conv3_thin<%s>", dn); *variant = name; return DC_OK; }
     if (use_ws) snprintf(name, sizeof(name), a.gn_scale ? "conv3_ws<%s,gn>" : "conv3_ws<%s>", dn);
-    else if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (halo_nw == 8 || a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
+    else if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && use_xreg) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
     else if (bn == 128 && !use_v1) {
       static const char* const shapes[4] = {"igemm_pipe<%s,128x128,2st>", "igemm_pipe<%s,256x128,3st>", "igemm_pipe<%s,256x256,2st>",
                                             "igemm_wide8<%s,256x256>"};
       const int shp = dc_igemm_pipe_shape(a);
-      snprintf(name, sizeof(name), shapes[shp == 2 && dc_igemm_wide8_enabled() ? 3 : shp], dn);
+      snprintf(name, sizeof(name), shapes[shp == 2 ? 3 : shp], dn);
     }
     else snprintf(name, sizeof(name), "igemm<%s,128x%d>", dn, bn);
     *variant = name;

@@ -141,9 +141,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 // defined in igemm_pipe.hip; returns DC_ERR_UNSUPPORTED-free status (always handles tile_n == 128)
 int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s);
 int dc_igemm_pipe_shape(const IgemmArgs& a);   // 0: 128x128, 1: 256x128, 2: 256x256 tile
-// igemm_wide.hip: the 256 x 256 tile on the 8-phase main loop (DCAMD_WIDE_OLD keeps the 2-stage loop of igemm_pipe.hip: A/B runs)
+// igemm_wide.hip: the 256 x 256 tile on the 8-phase main loop
 int dc_igemm_launch_wide8(const IgemmArgs& a, int dtype, hipStream_t s);
-bool dc_igemm_wide8_enabled();
 // hipcc expands the integer divisions of tile_of_block on the VECTOR unit, so tile_m / tile_n (and everything derived from them: weight
 // panel offsets, sample indices, descriptor bases) live in VGPRs although they are wave-uniform — and every `buffer_load ... lds` that
 // takes such a value as its SCALAR offset is wrapped in a waterfall loop (v_readfirstlane / v_cmp / s_and_saveexec / branch: ~10
@@ -159,7 +158,6 @@ __device__ __forceinline__ void tile_of_block_scalar(const IgemmArgs& a, int& ti
 
 // conv3_halo.hip
 bool dc_conv3_halo_applicable(const IgemmArgs& a, int dtype);
-bool dc_conv3_halo_gn_ok(const IgemmArgs& a, int dtype);   // fused GroupNorm prologue possible
 int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);
 bool dc_conv3_up4_applicable(const IgemmArgs& a, int dtype);   // upsample + 3x3 conv as four 2x2-tap phases
 int dc_conv3_up4_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);

@@ -28,9 +28,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // BM = 256, S = 3: 8 waves, 144 KiB, one workgroup per CU  — long K loops (3x3 convs, big-K GEMMs)
 // BM = 128, S = 2: 4 waves,  66 KiB, two workgroups per CU — short K loops, where the prologue/epilogue of
 //                  one workgroup must overlap the K loop of the other (K <= 512 spends most of a tile there)
-// NH = 2 (BM = 256, S = 2): 256 x 256 tile, each wave 64 pixels x 128 couts — 12 fragment reads per 32 MFMAs instead of
-//                  8 per 16 and a third less LDS-DMA per MFMA (the 64x64 wave tile is LDS-bandwidth bound at ~50 % of
-//                  the matrix pipe); wide layers (Cout a multiple of 256) with long K loops
+// NH: 64-cout halves per wave — always 1 here (the 256 x 256 tile, NH = 2, is igemm_wide.hip's 8-phase kernel)
 // EV: epilogue variant compiled in: -1 = all five behind a wave-uniform switch; 0 = plain, 2 = GEGLU, 3 = tanh-GELU, 4 = plain + gate.
 //     The 256x256 kernel holds 128 accumulator registers and is instantiated per variant (several variants in one
 //     kernel pushed hipcc into spilling accumulators inside the K loop).
@@ -38,7 +36,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //       kept the tap state live and cost the GEMMs ~20 %: it is a separate instantiation).
 template <typename T, int BM, int S, int NH, int EV, bool SLIM>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a) {
-  static_assert(NH == 1 || SLIM, "the wide tile takes 1-tap GEMMs only");
+  static_assert(NH == 1, "the 256 x 256 tile (NH = 2) moved to igemm_wide.hip in round 3; its 2-stage loop here was removed in round 4");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKE = 8 * EPC;
   constexpr int BN = 128 * NH;
@@ -221,31 +219,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
       lgkm_wait<3>(wf[1][0], wf[1][1], wf[1][2], wf[1][3], xf[1][0]);
       PIPE_MMA_GROUP(1, 0, 3) PIPE_MMA_GROUP(1, 1, 2) PIPE_MMA_GROUP(1, 2, 1) PIPE_MMA_GROUP(1, 3, 0)
 #undef PIPE_MMA_GROUP
-    } else if (NH == 2) {         // 256x256 tile: no short-M side path (rows past M read the zero page; big-M layers only)
-      const uint32_t stb = lds_addr_of(Xs);
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const uint32_t wa = stb + wfo[sub], xa = stb + xfo[sub];
-        chunk16 xf[TM], wf[TN];
-        lgkm_fence0();
-        wf[0] = ds_read16_async_off<0>(wa); wf[1] = ds_read16_async_off<2048>(wa);
-        wf[2] = ds_read16_async_off<4096>(wa); wf[3] = ds_read16_async_off<6144>(wa);
-        xf[0] = ds_read16_async_off<0>(xa); xf[1] = ds_read16_async_off<2048>(xa);
-        xf[2] = ds_read16_async_off<4096>(xa); xf[3] = ds_read16_async_off<6144>(xa);
-#define PIPE_MMA_GROUP2(H, J, NLEFT)                                                    \
-        lgkm_wait<NLEFT>(xf[J]);                                                          \
-        _Pragma("unroll") for (int i = 0; i < TN; ++i) acc[H][i][J] = Mma<T>::run(wf[i], xf[J], acc[H][i][J]);  \
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm_wait<3>(wf[0], wf[1], wf[2], wf[3], xf[0]);
-        PIPE_MMA_GROUP2(0, 0, 3) PIPE_MMA_GROUP2(0, 1, 2) PIPE_MMA_GROUP2(0, 2, 1) PIPE_MMA_GROUP2(0, 3, 0)
-        // second 64-cout half: its four weight fragments reuse the registers of the first (one short exposed LDS
-        // latency per 32-k sub-step, against 16 registers this kernel does not have)
-        wf[0] = ds_read16_async_off<8192>(wa); wf[1] = ds_read16_async_off<10240>(wa);
-        wf[2] = ds_read16_async_off<12288>(wa); wf[3] = ds_read16_async_off<14336>(wa);
-        lgkm_wait<0>(wf[0], wf[1], wf[2], wf[3], xf[0]);
-        PIPE_MMA_GROUP2(NH - 1, 0, 0) PIPE_MMA_GROUP2(NH - 1, 1, 0) PIPE_MMA_GROUP2(NH - 1, 2, 0) PIPE_MMA_GROUP2(NH - 1, 3, 0)
-#undef PIPE_MMA_GROUP2
-      }
     } else {                      // small-M side-path GEMMs: pixel tiles past M cost nothing (wave-uniform)
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
@@ -288,12 +261,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_pipe_kernel(const IgemmArgs a
     if (EV < 0) epi_direct<T, TM>(a, ac, tile128, half, lq, sf, sl, rowfn);
     else epi_direct_act<T, TM, (EV == 3 ? DC_ACT_GELU_TANH : (EV == 2 ? DC_ACT_GEGLU : DC_ACT_NONE)), EV == 4, false>(a, ac, tile128, half, lq, sf, sl, rowfn);   // EV 0 / 5: plain
   };
-  if (NH == 1) epi(acc[0], tile_n, wn);
-  else {
-    epi(acc[0], tile_n * 2 + wn, 0);
-    __builtin_amdgcn_sched_barrier(0);       // keep the second half's loads behind the first half's stores' issue: one epilogue's registers at a time
-    epi(acc[NH - 1], tile_n * 2 + wn, 1);
-  }
+  epi(acc[0], tile_n, wn);
 }
 
 template <typename T, int BM, int S, int NH, int EV, bool SLIM>
@@ -314,21 +282,13 @@ static int launch_pipe(const IgemmArgs& a0, hipStream_t s) {
   return dc_check_launch("dc_igemm(pipe)");
 }
 
-template <typename T>
-static int launch_wide(const IgemmArgs& a, hipStream_t s) {
-  if (a.act == DC_ACT_GELU_TANH) return launch_pipe<T, 256, 2, 2, 3, true>(a, s);
-  if (a.act == DC_ACT_GEGLU) return launch_pipe<T, 256, 2, 2, 2, true>(a, s);
-  if (a.gate) return launch_pipe<T, 256, 2, 2, 4, true>(a, s);
-  return launch_pipe<T, 256, 2, 2, 0, true>(a, s);
-}
-
-// 0: 128x128 / 2 stages, 1: 256x128 / 3 stages, 2: 256x256 / 2 stages
+// 0: 128x128 / 2 stages, 1: 256x128 / 3 stages, 2: 256x256 (igemm_wide.hip)
 int dc_igemm_pipe_shape(const IgemmArgs& a) {
-  static const int light_nk = getenv("DCAMD_PIPE_LIGHT_NK") ? atoi(getenv("DCAMD_PIPE_LIGHT_NK")) : 8;
+  constexpr int light_nk = 8;
   static const bool no_wide = getenv("DCAMD_PIPE_NO_WIDE") != nullptr;
-  static const long long wide_min_tiles = getenv("DCAMD_PIPE_WIDE_MIN_TILES") ? atoll(getenv("DCAMD_PIPE_WIDE_MIN_TILES")) : 400;
-  static const int wide_min_nk = getenv("DCAMD_PIPE_WIDE_MIN_NK") ? atoi(getenv("DCAMD_PIPE_WIDE_MIN_NK")) : 4;
-  const bool wide_act = a.act == DC_ACT_NONE || ((a.act == DC_ACT_GELU_TANH || a.act == DC_ACT_GEGLU) && !a.gate);   // the variants launch_wide has
+  constexpr long long wide_min_tiles = 400;
+  constexpr int wide_min_nk = 4;
+  const bool wide_act = a.act == DC_ACT_NONE || ((a.act == DC_ACT_GELU_TANH || a.act == DC_ACT_GEGLU) && !a.gate);   // the variants igemm_wide.hip has
   // 1-tap GEMMs on wide layers: the 256x256 tile whenever it fills the chip (>= wide_min_tiles tiles), whatever K
   if (!no_wide && wide_act && a.taps == 1 && (a.tiles_n & 1) == 0 && a.nk >= wide_min_nk &&
       (long long)((a.M + 255) / 256) * (a.tiles_n / 2) >= wide_min_tiles) return 2;
@@ -339,10 +299,6 @@ int dc_igemm_pipe_shape(const IgemmArgs& a) {
   const long long chip_tiles = ct ? atoll(ct) : 256;
   if ((long long)((a.M + 255) / 256) * a.tiles_n < chip_tiles) return 0;
   return 1;
-}
-
-bool dc_igemm_wide8_enabled() {
-  return getenv("DCAMD_WIDE_OLD") == nullptr;      // read per call (~0.1 us): tools/bench_wide_ab.py alternates the two loops inside one process
 }
 
 // four-phase upsample conv on the tap-gather kernel (sources smaller than 8x8): a0 as dc_igemm received it (upsampled extents)
@@ -372,12 +328,7 @@ int dc_igemm_launch_pipe(const IgemmArgs& a, int dtype, hipStream_t s) {
     if (dtype == DC_F16) return launch_pipe<_Float16, 128, 2, 1, -1, false>(a, s);
     return launch_pipe<float, 128, 2, 1, -1, false>(a, s);
   }
-  if (shape == 2) {
-    if (dc_igemm_wide8_enabled()) return dc_igemm_launch_wide8(a, dtype, s);
-    if (dtype == DC_BF16) return launch_wide<__bf16>(a, s);
-    if (dtype == DC_F16) return launch_wide<_Float16>(a, s);
-    return launch_wide<float>(a, s);
-  }
+  if (shape == 2) return dc_igemm_launch_wide8(a, dtype, s);     // the 256 x 256 tile lives in igemm_wide.hip (8-phase loop)
   if (slim) {
     if (dtype == DC_BF16) return launch_pipe<__bf16, 256, 3, 1, -1, true>(a, s);
     if (dtype == DC_F16) return launch_pipe<_Float16, 256, 3, 1, -1, true>(a, s);

@@ -239,7 +239,7 @@ bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype) {
   if (a.rowvec && a.Hout * a.Wout < 48) return false;     // a wave's 48 (32) rows must not span more than two samples
   // pays when the activation rows are reused across N tiles (measured: N = 2048 605 vs 317 TFLOP/s, N = 768 549 vs 333;
   // N = 256 equal, N = 128 slower than the tile kernel, whose two short tiles per CU overlap better)
-  static const int min_tiles = getenv("DCAMD_XREG_MIN_TILES") ? atoi(getenv("DCAMD_XREG_MIN_TILES")) : 3;
+  constexpr int min_tiles = 3;
   if (a.tiles_n < min_tiles) return false;
   if (a.Ktot > 512 || (a.Ktot & 63) || (a.C0 & 31) || (a.C1 & 31)) return false;
   return true;

@@ -637,12 +637,11 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   }
   // samples of up to 4 MiB: one workgroup per sample (gn_image_kernel).  The choice depends on (HW, C) only, never
   // on n, so a score does not depend on how many samples share a launch.
-  static const bool no_image = getenv("DCAMD_GN_SPLIT") != nullptr;
   const size_t img_bytes = (size_t)p->HW * C * dc_dtype_size(p->dtype);
-  static const size_t img_cap = getenv("DCAMD_GN_IMAGE_CAP") ? (size_t)atoll(getenv("DCAMD_GN_IMAGE_CAP")) : (4u << 20);
+  constexpr size_t img_cap = 4u << 20;
   // tiny samples without producer statistics: one wave per sample, register resident (gn_wave_kernel)
   static const bool no_wave = getenv("DCAMD_GN_NO_WAVE") != nullptr;
-  if (!no_wave && !no_image && !p->qstats && CP <= 64 && p->n < (1 << 30)) {
+  if (!no_wave && !p->qstats && CP <= 64 && p->n < (1 << 30)) {
     int tpr = 1; while (tpr < CP) tpr <<= 1;
     const int plw = 64 / tpr, nch = (p->HW + plw - 1) / plw;
     const size_t lds_w = (size_t)4 * (2 * C + 2 * p->groups) * sizeof(float);
@@ -657,17 +656,17 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
   // With the producer's statistics the normalise sweep needs no reduction across a sample, so a big sample is better spread
   // over many workgroups (gn_qfold_kernel + gn_apply_kernel, HW/256 splits) than streamed by ONE: the CheXpert / IPMSA plans
   // put only a few hundred 1-4 MiB samples into a launch (cfg3: 4.3 -> 5.x TB/s).  The threshold is a function of (HW, C) only.
-  static const size_t qsplit_min = getenv("DCAMD_GN_QSPLIT_MIN") ? (size_t)atoll(getenv("DCAMD_GN_QSPLIT_MIN")) : (1u << 20);
+  constexpr size_t qsplit_min = 1u << 20;
   const bool qsplit = p->qstats != nullptr && img_bytes >= qsplit_min;
   // producer statistics + a sample that divides into whole 16 KiB spans of one column set: gn_span_kernel (a function of (HW, C) only).
   // Default for samples of 1 MiB and more (the CheXpert / IPMSA plans, where it replaces gn_apply_kernel's split sweep: cfg3 +0.8 %,
-  // cfg4 +1.7 % per step); DCAMD_GN_SPAN forces it for every size, DCAMD_GN_NO_SPAN turns it off.  For the small samples of cfg2 it
+  // cfg4 +1.7 % per step); DCAMD_GN_SPAN forces it for every size (tests/test_gpu_ops.py).  For the small samples of cfg2 it
   // is NOT the default: alone it streams 5.9-6.4 TB/s against gn_image_kernel's 5.2-5.6, and inside the scoring step GroupNorm drops
   // from 11.1 to 10.1 ms — but the convolutions that follow slow down by the same amount (77.7 -> 77.9 ms per step): every kernel of
   // that step runs at the socket's power cap (~1.37 kW, 2.08-2.18 GHz by rocm-smi), so a phase that moves the same bytes in less
   // time only hands a hotter chip to the next phase.  DESIGN.md §6c.
-  static const bool span_all = getenv("DCAMD_GN_SPAN") != nullptr, span_never = getenv("DCAMD_GN_NO_SPAN") != nullptr;
-  const bool no_span = span_never || !(span_all || qsplit);      // default: only the samples of 1 MiB and more, which had the split apply sweep
+  static const bool span_all = getenv("DCAMD_GN_SPAN") != nullptr;
+  const bool no_span = !(span_all || qsplit);      // default: only the samples of 1 MiB and more, which had the split apply sweep
   const long long chunks = (long long)p->HW * CP;
   if (!no_span && p->qstats && C1 == 0 && CP <= 256 && (CP & (CP - 1)) == 0 && chunks % 1024 == 0 && p->groups <= 2048 &&
       (long long)p->n * (chunks / 1024) < (1LL << 31)) {
@@ -681,14 +680,13 @@ extern "C" int dc_groupnorm(const dc_groupnorm_params* p, dc_stream stream) {
     const int spans = (int)(chunks / 1024);
     const size_t lds_span = lds_apply + (size_t)(fold ? p->groups : p->qparts * (C >> 2)) * sizeof(float2);
     dim3 gs((unsigned)((long long)p->n * spans));
-    static const bool span_nt = getenv("DCAMD_GN_SPAN_NO_NT") == nullptr;
     if (p->dtype == DC_F32) hipLaunchKernelGGL((gn_span_kernel<float, false>), gs, blk, lds_span, s, a, spans);
-    else if (p->dtype == DC_BF16) { if (span_nt) hipLaunchKernelGGL((gn_span_kernel<__bf16, true>), gs, blk, lds_span, s, a, spans); else hipLaunchKernelGGL((gn_span_kernel<__bf16, false>), gs, blk, lds_span, s, a, spans); }
+    else if (p->dtype == DC_BF16) hipLaunchKernelGGL((gn_span_kernel<__bf16, true>), gs, blk, lds_span, s, a, spans);
     else if (p->dtype == DC_F16) hipLaunchKernelGGL((gn_span_kernel<_Float16, false>), gs, blk, lds_span, s, a, spans);
     else { dc_set_error("dc_groupnorm: dtype %d", p->dtype); return DC_ERR_DTYPE; }
     return dc_check_launch("dc_groupnorm(span)");
   }
-  if (!no_image && !qsplit && img_bytes <= img_cap && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
+  if (!qsplit && img_bytes <= img_cap && CP <= 512 && p->groups <= 512 && p->n < (1 << 30)) {
     a.qstats = p->qstats; a.qparts = p->qparts;
     int tpr = 1; while (tpr < CP) tpr <<= 1;
     const size_t lds_img = (size_t)2 * (512 / tpr) * C * sizeof(float);

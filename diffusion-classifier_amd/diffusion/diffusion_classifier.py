@@ -6,7 +6,8 @@ Kept surface (same names, argument meaning, assertions and return types):
   .evaluate(val_dataloader, stop_idx, metrics, classification)  reference :532-578
   .encode_text_prompt / .diffuse / .logsnr_schedule_cosine(_shifted)  :83-161
 `config` is the reference's attribute bag (missing keys read as None).  Additive keys read
-here: `compute_dtype` ("bf16" default | "f16" | "f32"), `units_per_launch`, `shard_grid` (opt-in: True
+here: `compute_dtype` ("bf16" default | "f16" | "f32"), `units_per_launch`, `score_plan_cache` (launch plans kept, LRU;
+default 6), `shard_grid` (opt-in: True
 shards the (trial, image) grid of ONE replicated batch over the default process group),
 `simulate_rank` ((r, N), bench.py only: time rank r's share of an N-rank sharded call on one GPU).
 
@@ -244,9 +245,12 @@ class DiffusionClassifier(nn.Module):
         z = z_t.detach().to(torch.float32).contiguous()
         out = torch.empty_like(z)
         patch = int(getattr(backbone.config, "patch_size", 0) or 0)
+        oc = int(getattr(backbone.config, "out_channels", Cc) or Cc)
+        if oc != Cc:        # dc_ddpm_step indexes the prediction with z's channel count as the feature stride
+            raise L.DcamdError(f"fused sampler step needs out_channels == in_channels (got {oc} vs {Cc})")
         p = L.DdpmStepParams(z=z.data_ptr(), pred=pair.data_ptr(), noise=None if noise is None else noise.data_ptr(), out=out.data_ptr(),
                              n=N, C=Cc, H=H, W=W, ld=pair.shape[-1], patch=patch, v_param=int(self.pred_param == 'v'),
-                             w=float(self.cfg_w), alpha_t=float(alpha_t), sigma_t=float(sigma_t), alpha_s=float(alpha_s), c=float(c), sd=float(sd))
+                             w=float(self.cfg_w), one_plus_w=float(1.0 + float(self.cfg_w)), alpha_t=float(alpha_t), sigma_t=float(sigma_t), alpha_s=float(alpha_s), c=float(c), sd=float(sd))
         L.check(L.lib().dc_ddpm_step(p, L.stream_ptr()), "dc_ddpm_step")
         return out
 
@@ -466,6 +470,7 @@ class _HipRunner:
                self.T, cfg.classes, wver)
         sp = dc._score_plans.get(key)
         if sp is not None:
+            dc._score_plans[key] = dc._score_plans.pop(key)      # most recently used last
             return sp
         # plans hold raw pointers into the packed weights they were built from: entries of an older weights version of this
         # backbone (load_state_dict / .to() / EMA.update since) are stale — drop them so their arenas are freed
@@ -493,6 +498,11 @@ class _HipRunner:
         plan = self.bb.make_plan(n_bj, k, cfg.classes, dev, score=score)
         sp = dict(plan=plan, score=score, ctl=ctl, pair_id=pair_id, words=words, n_bj=n_bj, k=k, U=U)
         dc._score_plans[key] = sp
+        # each entry owns an arena, a workspace and an errors buffer in HBM, and n_bj follows the pair count (per rank, per stage, per
+        # last batch of a dataloader): keep the most recently used few (a multi-stage classify alternates between one plan per stage)
+        cap = int(getattr(cfg, "score_plan_cache", None) or 6)
+        while len(dc._score_plans) > max(cap, 1):
+            del dc._score_plans[next(iter(dc._score_plans))]
         return sp
 
     def errors(self):

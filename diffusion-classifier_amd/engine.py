@@ -639,10 +639,6 @@ class UNetPlan:
 
     def __init__(self, model, weights, n_bj, n_cls, n_ctx, *, share_trunk=True, score=None, device=None):
         import os
-        # GroupNorm(+SiLU) folded into the consuming 3x3 conv's LDS prologue: measured ~1.5 % slower per step than
-        # the standalone apply pass on cfg2 (the in-loop transform costs the conv more than the pass it removes),
-        # so it stays opt-in until the transform overlaps the MFMA stream.
-        fuse_gn = os.environ.get("DCAMD_GN_FUSION") is not None
         fuse_gn_out = os.environ.get("DCAMD_NO_GN_OUT_FUSION") is None
         split_skips = os.environ.get("DCAMD_NO_SKIP_SPLIT") is None
         fold_short = os.environ.get("DCAMD_NO_SHORT_FOLD") is None
@@ -651,10 +647,9 @@ class UNetPlan:
         use_qs = os.environ.get("DCAMD_NO_QSTATS") is None
         use_up4 = os.environ.get("DCAMD_NO_UP4") is None
         fold_ln = os.environ.get("DCAMD_NO_LN_FOLD") is None
-        fold_ln_qkv = os.environ.get("DCAMD_LN_FOLD_QKV") is not None
         # GroupNorm(+SiLU) applied by the consuming 3x3 conv's loader waves (conv3_ws.hip) from the producer's quad records: no
         # GroupNorm launch, the normalised tensor never exists (DCAMD_NO_GN_WS: the GroupNorm pass + the plain conv, for A/B runs)
-        fuse_ws = os.environ.get("DCAMD_NO_GN_WS") is None and use_qs and not fuse_gn
+        fuse_ws = os.environ.get("DCAMD_NO_GN_WS") is None and use_qs
         cfg = model.config
         dev = device or weights.dev
         dt = weights.dt
@@ -733,15 +728,9 @@ class UNetPlan:
             # skip connection from the class-shared trunk into a per-class layer: conv(cat(h, skip)) = conv_a(h) + conv_b(skip)
             # and GroupNorm never mixes the two halves when its groups do not straddle the seam — the skip half is then
             # computed once per (image, trial) pair, not once per class.  Exact algebra; only the summation order differs.
-            split = (split_skips and not fuse_gn and x1 is not None and x1.dom == "bj" and x0.dom == "unit"
+            split = (split_skips and x1 is not None and x1.dom == "bj" and x0.dom == "unit"
                      and x0.C % ((x0.C + x1.C) // G) == 0 and key + ".conv_shortcut.w" in P)
-            # GroupNorm+SiLU is applied inside the conv's halo load where libdcamd can (the normalised tensor then never
-            # exists in HBM); otherwise as its own pass
-            if fuse_gn and pb.gn_fusable(x0, x1, Cout):
-                aff = pb.groupnorm_stats(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, x1=x1)
-                h = pb.igemm(key + ".conv1", x0, pb.const(P[key + ".conv1.w"]), Cout, taps=9, src1=x1,
-                             bias=pb.const(P[key + ".conv1.b"]), rowvec=tvec, gn=(aff[0], aff[1], True))
-            elif split:
+            if split:
                 # class-independent skip half, once per (image, trial) pair: its GroupNorm groups are its own, its conv
                 # partial sum enters the per-unit conv as a residual read through bj_of_unit
                 Ca, Cb = x0.C, x1.C
@@ -759,14 +748,11 @@ class UNetPlan:
                 h = pb.groupnorm(key + ".gn1", x0, pb.const(P[key + ".norm1.g"]), pb.const(P[key + ".norm1.b"]), G, eps, True, x1=x1)
                 h = pb.igemm(key + ".conv1", h, pb.const(P[key + ".conv1.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv1.b"]),
                              rowvec=tvec, qstats=use_qs)
-            fuse2 = fuse_gn and pb.gn_fusable(h, None, Cout)
             h_raw = h                  # conv1's output: conv2 normalises it itself where gn_conv3 can (norm2 + SiLU)
             n2g, n2b = pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"])
-            if fuse2:
-                aff2 = pb.groupnorm_stats(key + ".gn2", h, n2g, n2b, G, eps)
             # conv_shortcut folded into conv2: the 1x1 over the raw input becomes extra K chunks of conv2's own MFMA loop
             # (conv3_halo side source) — no shortcut launch, no shortcut tensor written and read back
-            fold = (fold_short and not fuse2 and key + ".conv_shortcut.w" in P and (x1 is None or split)
+            fold = (fold_short and key + ".conv_shortcut.w" in P and (x1 is None or split)
                     and pb.side_ok(h, x0, Cout, residual=x1 if split else None))
             if fold:
                 if key + ".conv2.bs" not in P:
@@ -785,9 +771,6 @@ class UNetPlan:
             else:
                 assert x1 is None
                 sc = x0
-            if fuse2:
-                return pb.igemm(key + ".conv2", h, pb.const(P[key + ".conv2.w"]), Cout, taps=9, bias=pb.const(P[key + ".conv2.b"]),
-                                residual=sc, gn=(aff2[0], aff2[1], True), qstats=use_qs)
             return gn_conv3(key + ".gn2", key + ".conv2", h_raw, n2g, n2b, G, pb.const(P[key + ".conv2.w"]), Cout,
                             bias=pb.const(P[key + ".conv2.b"]), residual=sc, qstats=use_qs)
 
@@ -798,12 +781,9 @@ class UNetPlan:
             h = pb.igemm(key + ".proj_in", h, pb.const(P[key + ".proj_in.w"]), Cc, bias=pb.const(P[key + ".proj_in.b"]))
             # LayerNorm folded into the consuming GEMM where the activation-stationary kernel can standardise the rows itself
             # (gamma into W's columns, beta into the bias: UNetWeights.fold_layernorms): no LayerNorm launch, no normalised tensor
-            if fold_ln_qkv and pb.ln_ok(h, 3 * Cc):      # measured: q/k/v is faster on the 256x256 tile + a LayerNorm launch (opt-in)
-                weights.fold_layernorms(tbk)
-                qkv = pb.igemm(tbk + ".qkv", h, pb.const(P[tbk + ".qkv.wf"]), 3 * Cc, bias=pb.const(P[tbk + ".qkv.bf"]), ln_eps=1e-5)
-            else:
-                hn = pb.layernorm(tbk + ".ln1", h, pb.const(P[tbk + ".norm1.g"]), pb.const(P[tbk + ".norm1.b"]), 1e-5)
-                qkv = pb.igemm(tbk + ".qkv", hn, pb.const(P[tbk + ".qkv.w"]), 3 * Cc)
+            # (q/k/v keeps its LayerNorm launch: measured faster on the 256x256 tile + LayerNorm than on the row-standardising GEMM)
+            hn = pb.layernorm(tbk + ".ln1", h, pb.const(P[tbk + ".norm1.g"]), pb.const(P[tbk + ".norm1.b"]), 1e-5)
+            qkv = pb.igemm(tbk + ".qkv", hn, pb.const(P[tbk + ".qkv.w"]), 3 * Cc)
             o = pb.attention(tbk + ".attn1", qkv.view(0, Cc), qkv.view(Cc, Cc), qkv.view(2 * Cc, Cc), heads)
             h = pb.igemm(tbk + ".attn_out", o, pb.const(P[tbk + ".attn1.to_out.0.w"]), Cc,
                          bias=pb.const(P[tbk + ".attn1.to_out.0.b"]), rowvec=cvec[key], residual=h)

@@ -36,8 +36,9 @@
 extern "C" {
 #endif
 
-/* 2: qstats records are (mean, M2) sets (version 1: sum, sum of squares) and qparts must divide HW */
-#define DC_ABI_VERSION 2
+/* 2: qstats records are (mean, M2) sets (version 1: sum, sum of squares) and qparts must divide HW
+ * 3: dc_ddpm_step_params.one_plus_w; dc_attention requires scale > 0 */
+#define DC_ABI_VERSION 3
 
 typedef void* dc_stream; /* hipStream_t */
 
@@ -212,7 +213,8 @@ int64_t dc_workspace_bytes_layernorm(const dc_layernorm_params* p);
 
 /* ---------------------------------------------------------------- attention ------ */
 /* softmax(q k^T * scale) v per (sample, head).  q/k/v: [n, L, heads, d] with row stride
- * ld (elements) so a fused QKV GEMM output can be passed as three offset pointers. */
+ * ld (elements) so a fused QKV GEMM output can be passed as three offset pointers.
+ * scale must be > 0 (DC_ERR_ARG otherwise): the kernels take the running max on the raw scores. */
 typedef struct {
   const void* q; const void* k; const void* v; void* out;
   int32_t dtype, n, L, heads, d, ld_qkv, ld_out; float scale;
@@ -239,12 +241,14 @@ int dc_eps_mse(const dc_eps_mse_params* p, dc_stream s);
  *   pred = (1 + w) * pred_c - w * pred_u;  x = v_param ? alpha_t z - sigma_t pred : (z - sigma_t pred) / alpha_t;  x = clip(x, -1, 1)
  *   mu = alpha_s * (z * (1 - c) / alpha_t + c * x);   out = noise ? mu + noise * sd : clip(mu, -1, 1)      (sd = sqrt(sigma_s^2 c))
  * z / noise / out [n, C, H, W] f32 NCHW; pred [2n, H, W, ld] f32 NHWC, rows 2b (class token) and 2b+1 (null token) of image b —
- * the output of ONE batch-2 backbone plan (patch > 1: DiT's un-patchified projection as in dc_eps_mse).  Same operation order as
- * the reference's torch expressions, no contraction: bit-equal to them for the same fp32 scalars. */
+ * the output of ONE batch-2 backbone plan (patch > 1: DiT's un-patchified projection as in dc_eps_mse, whose feature stride is C:
+ * the backbone's out_channels must equal C).  Same operation order as the reference's torch expressions, no contraction: equal to
+ * them bit for bit for the same fp32 scalars (w, one_plus_w, alpha_*, sigma_t, c, sd — formed by the caller). */
 typedef struct {
   const float* z; const float* pred; const float* noise; float* out;
   int32_t n, C, H, W, ld, patch, v_param;
   float w, alpha_t, sigma_t, alpha_s, c, sd;
+  float one_plus_w;        /* (float)(1.0 + (double)w): the reference forms 1 + w as a Python double and torch rounds it once */
 } dc_ddpm_step_params;
 int dc_ddpm_step(const dc_ddpm_step_params* p, dc_stream s);
 

@@ -39,7 +39,28 @@ def _worker(rank, world, port, name, q, mode="shard"):
     kw = dict(t=torch.from_numpy(g["t"]), eps=torch.from_numpy(g["eps"]),
               fast_select=torch.from_numpy(g["fast_select"]) if fast else None, return_errors=True)
     lab = torch.from_numpy(g["labels"]) if fast else None
-    if mode == "mismatch":
+    if mode == "history":
+        # the decision to compare the batch across ranks must not depend on anything rank-local.  Rank 0 allocates and
+        # frees junk between calls (another allocator history, other data_ptr values) and re-uses one buffer; rank 1 feeds fresh
+        # tensors.  Every rank must make the same collectives in the same order: five sharded classify calls complete with the
+        # golden labels, the checks made are the same calls on both ranks, and a batch that differs on a CHECKED call is refused.
+        from diffusion_classifier_amd import dist as D
+        made, buf = [], x.clone()
+        for i in range(5):
+            junk = [torch.empty(1000 + 977 * i * (rank + 1)) for _ in range(3 * (1 - rank))]
+            xi = buf if rank == 0 else x.clone()
+            n0 = D._replicated_calls.get(id(dist.group.WORLD), 0)
+            out, err = dc.classify(xi, lab, fast=fast, group=dist.group.WORLD, **kw)
+            made.append(n0 < D.REPLICATED_CHECK_FIRST or n0 % D.REPLICATED_CHECK_EVERY == 0)
+            del junk
+        D._replicated_calls[id(dist.group.WORLD)] = D.REPLICATED_CHECK_EVERY        # the next call is a checked one on every rank
+        try:
+            dc.classify(x + rank, lab, fast=fast, group=dist.group.WORLD, **kw)
+            verdict = "no error"
+        except RuntimeError as e:
+            verdict = "refused" if "identical image batch" in str(e) else repr(e)
+        q.put((rank, out.numpy(), (made, verdict)))
+    elif mode == "mismatch":
         # an accelerate-style launch (each rank holds its own images) with grid sharding requested: must be refused
         try:
             dc.classify(x + rank, lab, fast=fast, group=dist.group.WORLD, **kw)
@@ -101,6 +122,17 @@ def test_grid_sharding_is_opt_in_and_checks_that_x_is_replicated():
         np.testing.assert_array_equal(err, g["errors"])       # the full grid, computed locally, bit-equal to the reference
     for rank, verdict, _ in _spawn(2, "1stage_eps", "mismatch"):
         assert verdict == "refused", verdict
+
+
+def test_replicated_batch_check_is_a_rank_invariant_decision():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import load_case
+    g, _ = load_case("1stage_eps")
+    res = _spawn(2, "1stage_eps", "history")
+    for rank, out, (made, verdict) in res:
+        np.testing.assert_array_equal(out, g["out"])
+        assert made == [True, True, False, False, False], (rank, made)
+        assert verdict == "refused", (rank, verdict)
 
 
 def test_pair_ownership_is_a_balanced_partition():

@@ -1017,15 +1017,17 @@ def test_stage_topk_and_argmin_match_torch(shape):
     assert mp.cpu().tolist() == [[6, 0, (0 * 7 + 6) * 2 + 1, (0 * 7 + 0) * 2 + 1]]
 
 
-def test_ddpm_step_equals_the_torch_expressions():
+@pytest.mark.parametrize("w", [1.5, 0.1, 0.7000000000000001, 1e-8, 2.2, -1.0])
+def test_ddpm_step_equals_the_torch_expressions(w):
     """dc_ddpm_step (reference ddpm_sampler_step :175-208 + the update :262-266 as one pass): bit-equal to the reference's torch
     expressions for the same fp32 scalars — eps and v parameterisation, image-shaped and DiT-patch prediction layouts, the noise
-    update and the clipped mean of the last pass."""
+    update and the clipped mean of the last pass; several guidance weights (1 + w is formed as a Python double and rounded to fp32 once,
+    as torch does: for w = 1e-8 or 0.1 that is not 1.f + (float)w)."""
     torch.manual_seed(44)
     N, Cc, H, W = 3, 4, 8, 8
     z, noise = torch.randn(N, Cc, H, W), torch.randn(N, Cc, H, W)
     pc, pu = torch.randn(N, Cc, H, W) * 2, torch.randn(N, Cc, H, W) * 2
-    lt, ls, w = torch.tensor(-1.25), torch.tensor(0.75), 1.5
+    lt, ls = torch.tensor(-1.25), torch.tensor(0.75)
     c = -torch.special.expm1(lt - ls)
     a_t, a_s = torch.sqrt(torch.sigmoid(lt)), torch.sqrt(torch.sigmoid(ls))
     s_t, s_s = torch.sqrt(torch.sigmoid(-lt)), torch.sqrt(torch.sigmoid(-ls))
@@ -1046,7 +1048,7 @@ def test_ddpm_step_equals_the_torch_expressions():
             for nz, want in ((nd, mu + noise * sd), (None, torch.clamp(mu, -1, 1))):
                 out = torch.full((N, Cc, H, W), 9.0, device=DEV)
                 p = L.DdpmStepParams(z=ptr(zd), pred=ptr(pd), noise=ptr(nz), out=ptr(out), n=N, C=Cc, H=H, W=W, ld=ld, patch=patch,
-                                     v_param=v_param, w=w, alpha_t=float(a_t), sigma_t=float(s_t), alpha_s=float(a_s), c=float(c), sd=float(sd))
+                                     v_param=v_param, w=w, one_plus_w=float(1.0 + w), alpha_t=float(a_t), sigma_t=float(s_t), alpha_s=float(a_s), c=float(c), sd=float(sd))
                 L.check(L.lib().dc_ddpm_step(p, L.stream_ptr()), "dc_ddpm_step")
                 assert torch.equal(out.cpu(), want), (v_param, patch, (out.cpu() - want).abs().max())
 
