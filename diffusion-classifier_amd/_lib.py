@@ -40,7 +40,9 @@ class IgemmParams(C.Structure):
                 ("out", vp), ("out_dtype", i32), ("out_ld", i32),
                 ("gn_scale", vp), ("gn_shift", vp), ("gn_silu", i32), ("pad3_", i32),
                 ("src2", vp), ("map2", vp), ("W2", vp), ("C2", i32), ("ld2", i32),
-                ("ln_eps", f32), ("up4", i32), ("qstats", vp)]
+                ("ln_eps", f32), ("up4", i32), ("qstats", vp),
+                ("pn_out", vp), ("pn_gamma", vp), ("pn_beta", vp), ("pn_cnt", vp),
+                ("pn_ld", i32), ("pn_groups", i32), ("pn_silu", i32), ("pn_eps", f32)]
 
 
 class GroupnormParams(C.Structure):
@@ -82,7 +84,7 @@ class Op(C.Structure):
 
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
-           "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_igemm_side_ok", "dc_igemm_ln_ok", "dc_igemm_qstats_parts", "dc_igemm_up4_ok", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
+           "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_igemm_side_ok", "dc_igemm_ln_ok", "dc_igemm_qstats_parts", "dc_igemm_up4_ok", "dc_igemm_pn_ok", "dc_pn_timeouts", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
            "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_ddpm_step", "dc_haar_dwt2", "dc_haar_idwt2", "dc_stage_topk", "dc_reduce_argmin", "dc_stage_maps", "dc_run_plan", "dc_run_plan_timed",
            "dc_packed_bytes", "dc_pack_weights_matrix", "dc_pack_weights_conv3x3", "dc_pack_weights_up4", "dc_pack_weights_geglu",
            "dc_fold_layernorm_bias", "dc_workspace_bytes_groupnorm", "dc_workspace_bytes_igemm", "dc_workspace_bytes_attention",
@@ -138,6 +140,10 @@ def lib():
     L.dc_igemm_qstats_parts.restype = C.c_int32
     L.dc_igemm_up4_ok.argtypes = [C.POINTER(IgemmParams)]
     L.dc_igemm_up4_ok.restype = C.c_int32
+    L.dc_igemm_pn_ok.argtypes = [C.POINTER(IgemmParams)]
+    L.dc_igemm_pn_ok.restype = C.c_int32
+    L.dc_pn_timeouts.argtypes = []
+    L.dc_pn_timeouts.restype = C.c_int32
     L.dc_igemm_side_ok.argtypes = [C.POINTER(IgemmParams)]
     L.dc_igemm_side_ok.restype = C.c_int32
     L.dc_igemm_variant.argtypes = [C.POINTER(IgemmParams)]

@@ -33,6 +33,7 @@ struct HaloGeom {
   // readers keep one per-lane offset per column offset of the tap.  Used by the lock-step loops of conv3_halo.hip and by conv3_ws_kernel;
   // the staggered loop and the opt-in persistent kernels keep the plain image (conv3_halo.hip says why).
   int sws;
+  int lpt;                  // log2 of the tiles per image (producer-side GroupNorm: the workgroups that share a sample's statistics)
 };
 
 

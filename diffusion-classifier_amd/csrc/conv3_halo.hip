@@ -40,7 +40,9 @@ extern "C" void dc_debug_set_halo_abl(int v) { (void)hipMemcpyToSymbol(HIP_SYMBO
 #define DC_HALO_ABL() 0
 #endif
 #include "igemm_epilogue.h"
+#include "epi_pn.h"
 
+static __device__ unsigned g_pn_timeouts;     // producer-side GroupNorm: waves whose wait for their sample's statistics ran out (epi_pn.h)
 static __device__ chunk16 g_zero_page[16];   // per translation unit (no device-side linking)
 #include "conv3_halo.h"
 DC_CLOCK_DECL(conv3_halo)
@@ -67,8 +69,11 @@ DC_CLOCK_DECL(conv3_halo)
 //        instance 4s; the earliest re-stage (A, R_a(s)) comes after instance 4s+1.  X(cc+1) goes into X(cc-1)'s buffer: last read by
 //        B in R_b of the previous chunk's last step, retired before B arrives at the instance A's R_b of tap 0 waits behind.
 // One accumulator gets one MFMA per step in both loops: results are bit-identical.
-template <typename T, int NW, int NTAP = 9, int MODE = 0, bool STG = false>
+// PN (one image per patch, 4 waves, 3x3): producer-side GroupNorm — the output is stored normalised for the GroupNorm that consumes it
+// (epi_pn.h).  The workgroups of one (sample, N tile) then sit on consecutive block indices (see there).
+template <typename T, int NW, int NTAP = 9, int MODE = 0, bool STG = false, bool PN = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
+  static_assert(!PN || (MODE == 1 && NW == 4 && NTAP == 9 && !STG), "producer-side GroupNorm: the one-image-per-patch 3x3 form");
   static_assert(!STG || NW == 8, "staggered loop: the 8-wave kernel");
   constexpr bool XB = MODE == 1, MOS = MODE == 2;
   using Cfg = HaloCfg<NW>;
@@ -86,7 +91,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int wm = wave >> 1, wn = wave & 1;      // NW/2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
-  if constexpr (XB) tile_of_block_scalar(a, tile_m, tile_n);     // buffer-descriptor loaders: scalar offsets must be SGPRs (no waterfall loops)
+  if constexpr (PN) {      // group-major: block b = ((sample * tiles_n + N tile) << lpt) + tile of the image
+    const int grp = blockIdx.x >> g.lpt;
+    const int smp = grp / a.tiles_n;
+    tile_n = __builtin_amdgcn_readfirstlane(grp - smp * a.tiles_n);
+    tile_m = __builtin_amdgcn_readfirstlane((smp << g.lpt) + (blockIdx.x & ((1 << g.lpt) - 1)));
+    asm volatile("" : "+s"(tile_m), "+s"(tile_n));
+  } else if constexpr (XB) tile_of_block_scalar(a, tile_m, tile_n);     // buffer-descriptor loaders: scalar offsets must be SGPRs (no waterfall loops)
   else tile_of_block(a, tile_m, tile_n);
   constexpr bool UP4 = NTAP == 4;
   int phase = 0;
@@ -170,6 +181,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
       if (a.rowvec) v += a.rowvec[(size_t)(a.rowvec_map ? a.rowvec_map[ng] : ng) * a.rowvec_ld + c];
     }
     brv[t] = v;
+  }
+  if constexpr (PN) {      // gamma / beta of the consumer's GroupNorm for this N tile, behind the bias table
+    if (t >= 128 && t < 256) {
+      const int c = tile_n * 128 + t - 128;
+      brv[t] = a.pn_gamma[c];
+      brv[t + 128] = a.pn_beta[c];
+    }
   }
   __syncthreads();
   const char* zero = reinterpret_cast<const char*>(g_zero_page);      // wave-uniform (any 16 zero bytes do)
@@ -586,7 +604,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     r.o = UP4 ? n * (4 * HW) + (2 * (ty * th + py) + pa) * (2 * g.W) + 2 * (tx * tw + px) + pb : n * HW + rem;
     r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
   };
-  if constexpr (STAGE_BRV) {
+  if constexpr (PN) {
+    PnCtx pc;
+    pc.sample = ng; pc.part = ((ty * g.tiles_x + tx) << 1) + wm; pc.parts = HW >> 7; pc.tiles = 1 << g.lpt;
+    pc.qpg = (a.Cout / a.pn_groups) >> 2;
+    pc.cnt = a.pn_cnt + (size_t)ng * a.tiles_n + tile_n; pc.timeouts = &g_pn_timeouts;
+    pc.gam = brv + 128 + wn * 64 + lq * 8; pc.bet = brv + 256 + wn * 64 + lq * 8;
+    pc.scr = reinterpret_cast<float2*>(smem + wave * 4096);
+    pc.eps = a.pn_eps; pc.silu = a.pn_silu;
+    epi_halo_pn<T>(a, acc, tile_n, wn, lq, rowfn, brv + wn * 64 + lq * 8, pc);
+  } else if constexpr (STAGE_BRV) {
     epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, rowfn, EpiNoPre(), qsfn, HaloLdsBias{brv + wn * 64 + lq * 8});
   } else {
     epi_direct_act<T, TM, DC_ACT_NONE, false, !MOS>(a, acc, tile_n, wn, lq, nw0, nw1, rowfn, EpiNoPre(), qsfn);
@@ -837,6 +864,7 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   }
   g.inv_hp = g.hp ? 1.0f / (float)g.hp : 0.f; g.inv_hw = 1.0f / (float)g.hw;
   g.sws = (g.ltw < 4 ? g.ltw : 4) - 2;     // tw >= 16: 2, 8: 1, 4 (mosaic): 0
+  g.lpt = ilog2(g.tiles_x * g.tiles_y);
   {
     const long long hws = (long long)(a.upsample ? (g.H >> 1) * (g.W >> 1) : g.H * g.W);
     const long long ldmax = a.ld0 > a.ld1 ? (a.ld0 > a.ld2 ? a.ld0 : a.ld2) : (a.ld1 > a.ld2 ? a.ld1 : a.ld2);
@@ -850,6 +878,19 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
   if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, 4, 1> : conv3_halo_kernel<T, NW, 9, 1>;
+  if (a.pn_out) {
+    // producer-side GroupNorm (epi_pn.h): one-image-per-patch form only; dc_conv3_halo_pn_ok said so, this is the launch-time proof
+    if constexpr (NW == 4) {
+      if (!g.xbuf || up4 || ni != 1) { dc_set_error("conv3_halo: producer-side GroupNorm needs the one-image-per-patch 3x3 form"); return DC_ERR_SHAPE; }
+      static bool pn_attr = false;
+      kern = conv3_halo_kernel<T, 4, 9, 1, false, true>;
+      if (!pn_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS); pn_attr = true; }
+      // arrival counters, one per (sample, N tile): zeroed on the stream in front of every launch
+      if (hipMemsetAsync(a.pn_cnt, 0, (size_t)n_img * a.tiles_n * sizeof(unsigned), s) != hipSuccess) { dc_set_error("conv3_halo: counter memset failed"); return DC_ERR_LAUNCH; }
+    } else {
+      dc_set_error("conv3_halo: producer-side GroupNorm needs images of at least 16x16"); return DC_ERR_SHAPE;
+    }
+  }
   if constexpr (NW == 8) {
     if (g.mos) kern = up4 ? conv3_halo_kernel<T, NW, 4, 2> : conv3_halo_kernel<T, NW, 9, 2>;
     // staggered wave groups (STG) unless DCAMD_HALO_NO_STAG (read per call: A/B runs in one process)
@@ -870,6 +911,32 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
+}
+
+// producer-side GroupNorm (epi_pn.h): the conv must be the 4-wave one-image-per-patch form (power-of-two images of 16x16 ... 64x64: at
+// most 16 workgroups and 32 quad-record parts per sample), Cout a multiple of 128 whose GroupNorm groups are 4 ... 32 channels wide
+// (a group never leaves a wave's 64 channels); output (raw and normalised) in the compute type
+constexpr int PN_MAX_TILES = 16;
+bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype) {
+  static const bool off = getenv("DCAMD_NO_PN") != nullptr;
+  if (off || !dc_conv3_halo_applicable(a, dtype) || a.upsample || a.src1) return false;
+  const int H = a.Hin, W = a.Win;
+  if (H < 16 || W < 16 || H * W < 256 || (H * W) / 256 > PN_MAX_TILES) return false;
+  if (a.Cout % 128 || a.pn_groups <= 0 || a.Cout % a.pn_groups) return false;
+  const int cpg = a.Cout / a.pn_groups;
+  if (cpg != 4 && cpg != 8 && cpg != 16 && cpg != 32) return false;
+  const long long es = dc_dtype_size(dtype);
+  const long long ldmax = a.ld0 > a.ld2 ? a.ld0 : a.ld2;
+  if ((long long)H * W * ldmax * es >= (1LL << 31)) return false;                       // buffer-descriptor loaders (HaloGeom::xbuf)
+  if ((long long)a.tiles_n * 128 * a.Ktot * es >= (1LL << 31)) return false;
+  return true;
+}
+
+unsigned dc_conv3_halo_pn_timeouts() {
+  unsigned v = 0, z = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_pn_timeouts), sizeof(v)) != hipSuccess) return ~0u;
+  if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pn_timeouts), &z, sizeof(z));
+  return v;
 }
 
 // "nearest-2x upsample, then 3x3 conv" as four 2x2-tap phases on the low-resolution image (a.W: the phase-summed weights

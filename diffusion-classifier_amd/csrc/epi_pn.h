@@ -1,0 +1,261 @@
+// epi_pn.h — producer-side GroupNorm: the epilogue of a 3x3 halo conv that stores its output ALREADY normalised
+// (y = act(gn(v)), and optionally the raw v beside it) for the GroupNorm -> SiLU -> Conv2d / GroupNorm -> proj_in site that
+// consumes it (diffusers ResnetBlock2D.norm2 / norm1 of the next block, Transformer2DModel.norm; behind reference
+// nets/unet.py:186-195).
+//
+// Why: the GroupNorm between two convs is a pure read + write pass over the tensor (13-16 % of a UNet scoring step), and folding it
+// into the CONSUMER's loaders (conv3_ws.hip) costs that conv its second workgroup per CU (0.75 instead of 1.0-1.06 PF).  Here the
+// PRODUCER normalises: its accumulators already hold every value in fp32, the statistics it needs are the quad records it writes
+// anyway (igemm_epilogue.h, IgemmArgs::qstats), and the consumer stays the plain two-workgroup halo conv.  What a producer tile
+// lacks is the rest of its sample: a 256-pixel tile of a 32x32 image sees a quarter of every group.  So the workgroups of one
+// (sample, N tile) exchange their records through memory:
+//
+//   1. every wave writes its (mean, M2) quad records (one 128-pixel part x 16 quads) with agent-scope stores, waits for them,
+//      the workgroup meets at a barrier and ONE lane bumps the arrival counter of the (sample, N tile);
+//   2. every wave polls that counter (agent-scope loads, s_sleep between polls) until all `tiles` workgroups of the sample arrived;
+//   3. every wave copies the sample's records of ITS 64 channels into LDS (one record per lane and trip, all loads in flight
+//      together) and every lane folds the groups of its two 8-channel runs with gn_fold_rec — the GroupNorm kernels' own fold, same
+//      order, same instructions: the affine is bit-identical to what dc_groupnorm / gn_qaffine_kernel form from those records;
+//   4. raw store (if anyone reads the raw tensor), then y = act(v * a + b) in place and the normalised store.
+//
+// Forward progress: a workgroup waits only for workgroups of its own (sample, N tile), which the launch places on CONSECUTIVE
+// block indices (conv3_halo.hip, PN tile order).  Workgroups are dispatched in index order, so when one member of a group is
+// resident every earlier group is resident or finished, and the members not yet dispatched are next in line: they start as soon
+// as ANY resident workgroup of an earlier, complete group retires — which those can always do.  The host refuses groups larger
+// than a fraction of the chip's workgroup slots (dc_igemm_pn_ok).  The poll loop is bounded all the same (PN_TIMEOUT_TICKS of the
+// 100 MHz real-time counter): a wave that times out raises g_pn_timeouts (checked by the host, dc_pn_timeouts) and goes on with
+// whatever records are there — wrong numbers and an error, never a hang.
+#pragma once
+#include "igemm_epilogue.h"
+#include "gn_fold.h"
+
+#ifndef PN_TIMEOUT_TICKS
+#define PN_TIMEOUT_TICKS 3000000ull          // 30 ms at 100 MHz; a real wait is the dispatch skew inside one group (microseconds)
+#endif
+
+struct PnCtx {
+  int sample;            // output sample of the workgroup (one image per patch)
+  int part;              // this wave's 128-pixel part of the sample
+  int parts;             // parts per sample (HW / 128)
+  int tiles;             // workgroups per (sample, N tile) = HW / 256
+  int qpg;               // quads per GroupNorm group (channels per group / 4): 1, 2, 4 or 8
+  unsigned* cnt;         // arrival counter of this (sample, N tile); zeroed by the launch
+  unsigned* timeouts;    // library-wide failure counter
+  const float* gam;      // LDS: gamma / beta of the lane's run 0 (run k: 32 k floats further)
+  const float* bet;
+  float2* scr;           // LDS scratch of this WAVE, parts x 16 records: written only after the workgroup's barrier below
+  float eps;
+  int silu;
+};
+
+__device__ __forceinline__ void pn_store_rec(float* p, float x, float y) {
+  const unsigned long long v = ((unsigned long long)__builtin_bit_cast(unsigned, y) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, x);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// acc[i][j]: cout fragment i, pixel fragment j of the wave (128 pixels x 64 couts); brv: bias (+ row vector) of the lane's run 0 in LDS
+template <typename T, typename RowFn>
+__device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][8], int tile_n, int wn, int lq, RowFn rowfn,
+                                            const float* brv, const PnCtx& c) {
+  constexpr int TM = 8, NK = 2;
+  constexpr bool res16 = sizeof(T) == 2;
+  const int c0 = tile_n * 128 + wn * 64 + lq * 8;            // run k starts at c0 + 32 k (Cout is a multiple of 128: every run is real)
+  // ---- A1: bias + row vector (staged in LDS at kernel start) ----
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(brv + 32 * k), hi = *reinterpret_cast<const f32x4*>(brv + 32 * k + 4);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) { acc[2 * k][j] += lo; acc[2 * k + 1][j] += hi; }
+  }
+  DC_STAMP(3);
+  // ---- A2: residual, every load of the wave in front of every store (vmcnt is one in-order counter) ----
+  int orow[TM];
+  {
+    EpiRow row[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) { rowfn(j, row[j]); orow[j] = row[j].o; }
+    if (a.residual) {
+      if (res16) {
+        chunk16 rc[TM][NK];
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+            rc[j][k] = *reinterpret_cast<const chunk16*>(reinterpret_cast<const char*>(a.residual) + ((size_t)row[j].r * a.res_ld + c0 + 32 * k) * 2);
+        DC_STAMP(4);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            float rf[8];
+            chunk_to_f<T>(rc[j][k], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[2 * k + (e >> 2)][j][e & 3] += rf[e];
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            float rf[8];
+            ld8(reinterpret_cast<const float*>(a.residual) + (size_t)row[j].r * a.res_ld + c0 + 32 * k, rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[2 * k + (e >> 2)][j][e & 3] += rf[e];
+          }
+      }
+    }
+  }
+  DC_STAMP(5);
+  // ---- quad statistics of the wave's part: the arithmetic of igemm_epilogue.h's `emit` (whole-wave form), so that the records
+  // are the ones a plain conv3_halo launch writes into IgemmArgs::qstats ----
+  {
+#pragma clang fp contract(off)
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    auto share0 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xF, 0xF, true)); };
+    auto row_sum = [](float v) {
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+      return v;
+    };
+    float piv[NK][2];
+    f32x2 sm[NK][2], sq[NK][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int qd = 0; qd < 2; ++qd) {
+        piv[k][qd] = share0(acc[2 * k + qd][0][0]);
+        sm[k][qd] = f32x2{0.f, 0.f}; sq[k][qd] = f32x2{0.f, 0.f};
+      }
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 d = f32x2{acc[2 * k + qd][j][e], acc[2 * k + qd][j][e + 1]} - f32x2{piv[k][qd], piv[k][qd]};
+            sm[k][qd] += d;
+            sq[k][qd] = __builtin_elementwise_fma(d, d, sq[k][qd]);
+          }
+    const float inv_n = 1.0f / (float)(TM * 16 * 4);
+    float r[NK][4];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int qd = 0; qd < 2; ++qd) {
+        const float S = row_sum(sm[k][qd][0] + sm[k][qd][1]), Q = row_sum(sq[k][qd][0] + sq[k][qd][1]);
+        r[k][2 * qd] = __builtin_fmaf(S, inv_n, piv[k][qd]);
+        r[k][2 * qd + 1] = fmaxf(__builtin_fmaf(-S * S, inv_n, Q), 0.f);
+      }
+    if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        float* p = a.qstats + (((size_t)c.sample * c.parts + c.part) * (a.Cout >> 2) + ((c0 + 32 * k) >> 2)) * 2;
+        pn_store_rec(p, r[k][0], r[k][1]);
+        pn_store_rec(p + 2, r[k][2], r[k][3]);
+      }
+    }
+  }
+  // ---- 1./2. publish, arrive, wait for the rest of the sample ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my records are acknowledged by the memory side
+  __syncthreads();                                           // ... and so are the other waves'; every wave has left the tap loop (LDS is free)
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool ok = false;
+  {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (seen >= (unsigned)c.tiles) { ok = true; break; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > PN_TIMEOUT_TICKS) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  DC_STAMP(6);
+  // ---- 3. the sample's records of this wave's 16 quads -> LDS, then fold the lane's groups ----
+  {
+    const int lane = threadIdx.x & 63;
+    const int CQ = a.Cout >> 2;
+    const unsigned long long* recg = reinterpret_cast<const unsigned long long*>(a.qstats) + (size_t)c.sample * c.parts * CQ + ((tile_n * 128 + wn * 64) >> 2);
+    const int nrec = c.parts * 16;
+#pragma unroll 4
+    for (int i = lane; i < nrec; i += 64) {
+      const unsigned long long v = __hip_atomic_load(recg + (size_t)(i >> 4) * CQ + (i & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c.scr[i] = float2{__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32))};
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): the wave's own LDS writes (its lanes read each other's records)
+  __builtin_amdgcn_wave_barrier();
+  float ga[NK][8], gb[NK][8];
+  {
+    const float nq = 512.0f;                                 // values per record: 128 pixels x 4 channels
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int ql = 2 * lq + 8 * k;                         // the run's first quad among the wave's 16
+      float mean[2], rstd[2];
+      if (c.qpg == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const GnAcc A = gn_fold_rec(c.scr, c.parts, 16, ql + h, 1, nq);
+          mean[h] = A.mean; rstd[h] = rsqrtf(A.var() + c.eps);
+        }
+      } else {
+        const GnAcc A = gn_fold_rec(c.scr, c.parts, 16, ql / c.qpg, c.qpg, nq);
+        mean[0] = mean[1] = A.mean; rstd[0] = rstd[1] = rsqrtf(A.var() + c.eps);
+      }
+      if (!ok) rstd[0] = rstd[1] = __builtin_nanf("");     // a timed-out wait: poison what is stored, so the failure also shows downstream
+      float gm[8], bt[8];
+      ld8(c.gam + 32 * k, gm);
+      ld8(c.bet + 32 * k, bt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float s = rstd[e >> 2] * gm[e];
+        ga[k][e] = s; gb[k][e] = bt[e] - mean[e >> 2] * s;
+      }
+    }
+  }
+  // ---- 4. stores: raw (if it has a reader), then the normalised tensor ----
+  if (a.out) {
+    if (a.out_dtype == DC_F32) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          float* op = reinterpret_cast<float*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k;
+          *reinterpret_cast<f32x4*>(op) = acc[2 * k][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2 * k + 1][j];
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[2 * k + (e >> 2)][j][e & 3];
+          *reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k) = f_to_chunk<T>(v);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = acc[2 * k + (e >> 2)][j][e & 3] * ga[k][e] + gb[k][e];
+        if (c.silu) x = silu_t<T>(x);
+        v[e] = x;
+      }
+      T* op = reinterpret_cast<T*>(a.pn_out) + (size_t)orow[j] * a.pn_ld + c0 + 32 * k;
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        *reinterpret_cast<chunk16*>(op) = f_to_chunk<T>(v);
+      }
+    }
+}

@@ -193,6 +193,22 @@ extern "C" int32_t dc_igemm_qstats_parts(const dc_igemm_params* p) {
   return hw >= 128 ? hw / 128 : 1;          // one part per wave-sized run of 128 pixels (64-pixel images: one)
 }
 
+extern "C" int32_t dc_igemm_pn_ok(const dc_igemm_params* p) {
+  if (!p || p->pn_groups <= 0) return 0;
+  dc_igemm_params q = *p;
+  alignas(16) static float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!q.pn_out) q.pn_out = dummy;
+  if (!q.qstats) q.qstats = dummy;
+  if (!q.pn_gamma) q.pn_gamma = dummy;
+  if (!q.pn_beta) q.pn_beta = dummy;
+  if (!q.pn_cnt) q.pn_cnt = reinterpret_cast<uint32_t*>(dummy);
+  if (!(q.pn_eps > 0.f)) q.pn_eps = 1e-5f;
+  const char* v = nullptr;
+  return igemm_run(&q, nullptr, &v) == DC_OK ? 1 : 0;
+}
+
+extern "C" int32_t dc_pn_timeouts(void) { return (int32_t)dc_conv3_halo_pn_timeouts(); }
+
 extern "C" int32_t dc_igemm_up4_ok(const dc_igemm_params* p) {
   if (!p) return 0;
   dc_igemm_params q = *p;
@@ -223,7 +239,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   DC_REQUIRE(p->taps == 1 || p->taps == 9, DC_ERR_ARG, "dc_igemm: taps must be 1 or 9 (got %d)", p->taps);
   DC_REQUIRE(p->stride == 1 || p->stride == 2, DC_ERR_ARG, "dc_igemm: stride %d", p->stride);
   DC_REQUIRE(p->tile_n == 128 || p->tile_n == 32, DC_ERR_ARG, "dc_igemm: tile_n %d", p->tile_n);
-  DC_REQUIRE(p->src0 && p->W && p->out, DC_ERR_ARG, "dc_igemm: null src0/W/out");
+  DC_REQUIRE(p->src0 && p->W && (p->out || p->pn_out), DC_ERR_ARG, "dc_igemm: null src0/W/out");
   const int bke = 128 / dc_dtype_size(p->dtype);
   DC_REQUIRE(p->C0 > 0 && p->C0 % bke == 0, DC_ERR_SHAPE, "dc_igemm: C0=%d not a multiple of %d", p->C0, bke);
   DC_REQUIRE(p->C1 >= 0 && p->C1 % bke == 0 && ((p->C1 > 0) == (p->src1 != nullptr)), DC_ERR_SHAPE,
@@ -260,6 +276,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   a.gn_scale = p->gn_scale; a.gn_shift = p->gn_shift; a.gn_silu = p->gn_silu;
   a.src2 = p->src2; a.map2 = p->map2; a.W2 = p->W2; a.C2 = p->C2; a.ld2 = p->ld2 ? p->ld2 : p->C2;
   a.ln_eps = p->ln_eps; a.qstats = p->qstats;
+  a.pn_out = p->pn_out; a.pn_gamma = p->pn_gamma; a.pn_beta = p->pn_beta; a.pn_cnt = reinterpret_cast<unsigned*>(p->pn_cnt);
+  a.pn_ld = p->pn_ld ? p->pn_ld : p->Cout; a.pn_groups = p->pn_groups; a.pn_silu = p->pn_silu; a.pn_eps = p->pn_eps;
   DC_REQUIRE((p->gn_scale == nullptr) == (p->gn_shift == nullptr), DC_ERR_ARG, "dc_igemm: gn_scale/gn_shift must both be set or null");
   a.C0 = p->C0; a.C1 = p->C1; a.ld0 = p->ld0 ? p->ld0 : p->C0; a.ld1 = p->ld1 ? p->ld1 : p->C1;
   a.rowvec_ld = p->rowvec_ld; a.gate_ld = p->gate_ld; a.res_dtype = p->res_dtype;
@@ -285,7 +303,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   // the LDS-DMA kernels finish with the lane-resident epilogue (igemm_epilogue.h): whole 16-byte runs of 8 channels in
   // and out.  Anything else (channel counts / leading dimensions that are not multiples of 8, unaligned side
   // operands) takes the register-staged kernel, whose element-wise epilogue handles every case.
-  const bool lane_epi_ok = cout_out % 8 == 0 && p->out_ld % 8 == 0 && ((uintptr_t)p->out & 15) == 0 &&
+  const bool lane_epi_ok = cout_out % 8 == 0 && p->out_ld % 8 == 0 && ((uintptr_t)p->out & 15) == 0 &&      // (a null `out`: producer-side GroupNorm only)
                            (!p->residual || (p->res_ld % 8 == 0 && ((uintptr_t)p->residual & 15) == 0)) &&
                            (!p->bias || ((uintptr_t)p->bias & 15) == 0) &&
                            (!p->rowvec || (((uintptr_t)p->rowvec & 15) == 0 && p->rowvec_ld % 4 == 0)) &&
@@ -350,6 +368,20 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
       return DC_ERR_UNSUPPORTED;
     }
   }
+  // producer-side GroupNorm: the caller opted in (dc_igemm_pn_ok), anything that cannot take it is an error
+  const bool use_pn = a.pn_out != nullptr;
+  if (use_pn) {
+    const bool pn_ok = halo_ok && !use_ws && !a.gn_scale && !dc_conv3_thin_applicable(a, p->dtype) && dc_conv3_halo_pn_ok(a, p->dtype) &&
+                       a.qstats && a.pn_gamma && a.pn_beta && a.pn_cnt && p->out_dtype == p->dtype && a.pn_ld % 8 == 0 && a.pn_ld >= p->Cout &&
+                       (((uintptr_t)a.pn_out | (uintptr_t)a.qstats) & 15) == 0 && ((uintptr_t)a.pn_cnt & 3) == 0 && a.pn_eps > 0.f;
+    if (!pn_ok) {
+      if (variant) { *variant = "producer-groupnorm-unsupported"; return DC_ERR_UNSUPPORTED; }
+      dc_set_error("dc_igemm: pn_out given but this problem cannot normalise its own output (see dc_igemm_pn_ok)");
+      return DC_ERR_UNSUPPORTED;
+    }
+  } else {
+    DC_REQUIRE(p->out, DC_ERR_ARG, "dc_igemm: null out");
+  }
   // short-K GEMMs: the activation-stationary kernel wins for GEGLU (448 vs 376 TFLOP/s at K = 256, 584 vs 544 at K = 512);
   // for plain epilogues the 256x256 tile is faster where it applies (q/k/v 505-709 vs 478-556), xreg elsewhere
   const bool ln_ok = bn == 128 && !use_v1 && !a.src1 && dc_igemm_xreg_applicable(a, p->dtype);
@@ -364,6 +396,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     static thread_local char name[64];
     if (thin) { snprintf(name, sizeof(name), "conv3_thin<%s>", dn); *variant = name; return DC_OK; }
     if (use_ws) snprintf(name, sizeof(name), a.gn_scale ? "conv3_ws<%s,gn>" : "conv3_ws<%s>", dn);
+    else if (use_pn) snprintf(name, sizeof(name), "conv3_halo<%s,4w,pn>", dn);
     else if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && use_xreg) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
     else if (bn == 128 && !use_v1) {

@@ -14,6 +14,9 @@ struct IgemmArgs {
   const void* src2; const int32_t* map2; const void* W2; int C2, ld2;   // 1x1 side source (conv3_halo only)
   float ln_eps;             // > 0: row LayerNorm of the A operand (igemm_xreg only)
   float* qstats;            // per (sample, part, channel quad) (mean, M2) of the stored output (conv3_halo only)
+  // producer-side GroupNorm (epi_pn.h; conv3_halo one-image-per-patch form only): pn_out receives act(gn(v)) of the output v, `out`
+  // (may then be null) the raw v; pn_cnt: one zeroed arrival counter per (sample, N tile)
+  void* pn_out; const float* pn_gamma; const float* pn_beta; unsigned* pn_cnt; int pn_ld, pn_groups, pn_silu; float pn_eps;
   int C0, C1, ld0, ld1, rowvec_ld, gate_ld, res_dtype, res_ld, out_dtype, out_ld, act;
   int taps, stride, upsample, Hin, Win, Hout, Wout, Cout;
   int M, Ktot, c0chunks, cpt, nk, tiles_m, tiles_n;
@@ -162,6 +165,8 @@ int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s
 bool dc_conv3_up4_applicable(const IgemmArgs& a, int dtype);   // upsample + 3x3 conv as four 2x2-tap phases
 int dc_conv3_up4_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);
 int dc_igemm_launch_pipe_up4(const IgemmArgs& a, int dtype, hipStream_t s);   // the same on the tap-gather kernel (sources < 8x8)
+bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype);      // producer-side GroupNorm possible (epi_pn.h)
+unsigned dc_conv3_halo_pn_timeouts();                          // reads and clears the device-side failure counter (synchronous)
 // conv3_ws.hip: wave-specialised halo conv (loader / transform waves + MFMA waves) with the input's GroupNorm(+SiLU) fused in
 bool dc_conv3_ws_ok(const IgemmArgs& a, int dtype);
 int dc_conv3_ws_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);

@@ -7,6 +7,7 @@
 // (fixed-order) reductions — no float atomics.
 #include <stdlib.h>
 #include "common.h"
+#include "gn_fold.h"
 
 // ------------------------------------------------------------------ GroupNorm -----
 // Statistics are carried as (mean, M2 = sum (v - mean)^2) of value sets — per thread, per split, per producer record — and
@@ -22,18 +23,6 @@ struct GnArgs {
   int wsplits;                          // partial records per sample in ws (= splits, or 1 after gn_qfold_kernel)
 };
 
-// running (count, mean, M2); add() merges another set (Chan et al.), in the order the caller walks — fixed everywhere below
-struct GnAcc {
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  __device__ __forceinline__ void add(float n2, float mean2, float m22) {
-    if (n2 <= 0.f) return;
-    const float nt = n + n2, d = mean2 - mean, w = n2 / nt;
-    mean += d * w;
-    m2 += m22 + d * d * (n * w);
-    n = nt;
-  }
-  __device__ __forceinline__ float var() const { return n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f; }     // a division: never contracted
-};
 // merge of many (count, mean, M2) sets in ONE pass without a division per set: shifted by the first set's mean,
 // N = sum n, S1 = sum n d, S3 = sum n d^2 (d = mean - pivot), S2 = sum M2  ->  mean = pivot + S1/N, M2 = S2 + S3 - S1^2/N
 struct GnMerge {
@@ -74,29 +63,6 @@ __device__ __forceinline__ GnAcc gn_fold_ws(const GnArgs& a, int n, int g, int c
   }
   return A;
 }
-// fold the producer's quad records of group g (rec: [part][C/4] float2 (mean, M2) of the sample, each over nq = 4 * HW / qparts
-// values): equal counts, so mean = average of the means and M2 = sum M2_r + nq * sum (mean_r - mean)^2.  One pass, parts outer,
-// the group's quads inner, the means shifted by the first record's (what is left inside the shifted sums is the spread of the
-// record means, which is part of the group's variance): as many loads as the sum / sum-of-squares form had, no division per record
-__device__ __forceinline__ GnAcc gn_fold_rec(const float2* rec, int qparts, int CQ, int g, int qpg, float nq) {
-  // inlined into four kernels (image / span / affine sweeps) that must agree bit for bit: no implicit contraction
-#pragma clang fp contract(off)
-  const float piv = rec[g * qpg].x;
-  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int part = 0; part < qparts; ++part)
-    for (int q = g * qpg; q < (g + 1) * qpg; ++q) {
-      const float2 v = rec[(size_t)part * CQ + q];
-      const float d = v.x - piv;
-      s1 += d; s3 = __builtin_fmaf(d, d, s3); s2 += v.y;
-    }
-  const float R = (float)(qparts * qpg), iR = 1.0f / R;
-  GnAcc A;
-  A.n = R * nq;
-  A.mean = __builtin_fmaf(s1, iR, piv);
-  A.m2 = __builtin_fmaf(nq, fmaxf(__builtin_fmaf(-s1 * s1, iR, s3), 0.f), s2);
-  return A;
-}
-
 // Two launches for samples too large for one workgroup.  stats: grid (splits, n); each block reduces its pixel slice of one
 // sample to per-group (mean, M2) partials.  apply: same grid; each block folds the `splits` partials of its sample in fixed
 // order, then normalises (+affine, +SiLU) its pixel slice.

@@ -41,13 +41,14 @@ def round_up(a, b):
 
 class TRef:
     """Handle of a plan tensor [n(dom), H, W, C] (NHWC) or a view of one."""
-    __slots__ = ("name", "dom", "H", "W", "C", "dt", "ld", "eoff", "base", "nbytes", "first", "last", "off", "ext", "qs")
+    __slots__ = ("name", "dom", "H", "W", "C", "dt", "ld", "eoff", "base", "nbytes", "first", "last", "off", "ext", "qs", "prod")
 
     def __init__(self, name, dom, H, W, C, dt, nbytes=0, ext=None):
         self.name, self.dom, self.H, self.W, self.C, self.dt = name, dom, H, W, C, dt
         self.ld, self.eoff, self.base = C, 0, self
         self.nbytes, self.first, self.last, self.off, self.ext = nbytes, None, None, None, ext
         self.qs = None       # (quad-statistics tensor, parts) written by the producing conv (dc_igemm_params.qstats)
+        self.prod = None     # index of the producing dc_igemm op while it can still be asked to normalise this tensor (pn_claim)
 
     def view(self, coff, C):
         v = TRef(self.name + f"[{coff}:{coff + C}]", self.dom, self.H, self.W, C, self.dt)
@@ -65,6 +66,8 @@ class PlanBuilder:
         self.arena = None
         self.arena_bytes = 0
         self.meta = []       # per op: name, kernel family, algorithmic flops / HBM bytes (bench.py roofline)
+        import os
+        self.pn_off = os.environ.get("DCAMD_NO_PN") is not None      # A/B runs and tests: never ask a producer to normalise
 
     # ---- tensors -------------------------------------------------------------------
     def tensor(self, name, dom, H, W, Cc, dt):
@@ -174,7 +177,36 @@ class PlanBuilder:
             meta["flops"] += 2.0 * M * side[0].C * Cout
             meta["K"] = kreal + side[0].C
         self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []) + ([side[0]] if side else []), [out] + ([qs] if qs else []), meta)
+        if qs is not None and gn is None:
+            out.prod = len(self.ops) - 1
         return out
+
+    def pn_claim(self, x, gamma, beta, groups, eps, silu):
+        """Producer-side GroupNorm (dc_igemm_params.pn_*; csrc/epi_pn.h): ask the 3x3 conv that produced x to ALSO store
+        act(GroupNorm(x)) — its accumulators hold every value in fp32 and it writes the statistics anyway — so that the consumer of
+        this GroupNorm reads a finished tensor with a plain conv / GEMM and no GroupNorm pass (nor a normalising loader) runs.
+        Returns the normalised tensor, or None when the producer cannot (then the caller takes the GroupNorm pass / the fused loader).
+        One claim per tensor; whether the raw x is still stored is decided in finalize() (only if something reads it)."""
+        if x is None or x.prod is None or x.base is not x or self.pn_off or L.lib().dc_igemm_pn_ok is None:
+            return None
+        idx = x.prod
+        kind, cls, f = self.ops[idx]
+        if f.get("pn_out") is not None or f["Cout"] % groups:
+            return None
+        fake = 1 << 20
+        probe = L.IgemmParams(**{k: (fake if isinstance(v, TRef) else v) for k, v in f.items() if v is not None}, pn_groups=groups, pn_eps=float(eps))
+        if not L.lib().dc_igemm_pn_ok(probe):
+            return None
+        dom = x.dom
+        y = self.tensor(x.name + ".pn", dom, x.H, x.W, x.C, x.dt)
+        cnt = TRef(x.name + ".pncnt", dom, 1, 1, 1, L.DC_F32, nbytes=round_up(self.n[dom] * ((f["Cout"] + 127) // 128) * 4, 256))
+        for t in (y, cnt):
+            t.first = t.last = idx
+        f.update(pn_out=y, pn_gamma=gamma, pn_beta=beta, pn_cnt=cnt, pn_ld=y.ld, pn_groups=groups, pn_silu=int(silu), pn_eps=float(eps))
+        self.meta[idx]["bytes"] += float(self.n[dom] * x.H * x.W * x.C * DT_SIZE[x.dt])
+        self.meta[idx]["pn"] = True
+        x.prod = None
+        return y
 
     def up4_ok(self, src0, Cout):
         """Can the upsample conv of src0 run as four 2x2-tap phases on the low-resolution image (dc_igemm_up4_ok)?"""
@@ -321,6 +353,13 @@ class PlanBuilder:
         nops = len(self.ops)
         for t in keep_alive:
             t.base.last = nops
+        # a producer-normalised conv whose raw output nobody reads stores only the normalised tensor
+        for i, (kind, _, f) in enumerate(self.ops):
+            if kind == L.OP_IGEMM and f.get("pn_out") is not None and isinstance(f.get("out"), TRef):
+                b = f["out"].base
+                if b.ext is None and b.first == i and b.last == i:
+                    self.meta[i]["bytes"] -= float(self.n[b.dom] * b.H * b.W * b.C * DT_SIZE[b.dt])
+                    f["out"] = None
         bases = {}
         for _, _, f in self.ops:
             for v in f.values():
@@ -716,6 +755,10 @@ class UNetPlan:
             in kw).  One launch where the wave-specialised conv can normalise its own input (affine from the quad records x's
             producer wrote: no pass over x at all); else the GroupNorm pass and the plain conv."""
             dom = pb._dom(x, kw.get("rowvec"), kw.get("residual"), kw["side"][0] if kw.get("side") else None)
+            # first choice: x's producer stores the normalised tensor itself (csrc/epi_pn.h) and this conv is the plain halo conv
+            y = pb.pn_claim(x, gamma, beta, groups, eps, True)
+            if y is not None:
+                return pb.igemm(cname, y, Wp, Cout, taps=9, **kw)
             if fuse_ws and dom == x.dom and pb.qstats_ok(x, None, groups, dom) and pb.gn_ws_ok(x, Cout):
                 aff = pb.groupnorm_stats(gname, x, gamma, beta, groups, eps)
                 return pb.igemm(cname, x, Wp, Cout, taps=9, gn=(aff[0], aff[1], True), **kw)
@@ -777,7 +820,9 @@ class UNetPlan:
         def transformer(key, x):
             Cc = x.C
             tbk = key + ".transformer_blocks.0"
-            h = pb.groupnorm(key + ".gn", x, pb.const(P[key + ".norm.g"]), pb.const(P[key + ".norm.b"]), G, 1e-6, False)
+            h = pb.pn_claim(x, pb.const(P[key + ".norm.g"]), pb.const(P[key + ".norm.b"]), G, 1e-6, False)
+            if h is None:
+                h = pb.groupnorm(key + ".gn", x, pb.const(P[key + ".norm.g"]), pb.const(P[key + ".norm.b"]), G, 1e-6, False)
             h = pb.igemm(key + ".proj_in", h, pb.const(P[key + ".proj_in.w"]), Cc, bias=pb.const(P[key + ".proj_in.b"]))
             # LayerNorm folded into the consuming GEMM where the activation-stationary kernel can standardise the rows itself
             # (gamma into W's columns, beta into the bias: UNetWeights.fold_layernorms): no LayerNorm launch, no normalised tensor
@@ -837,7 +882,11 @@ class UNetPlan:
                 else:
                     h = pb.igemm(key, h, pb.const(P[key + ".w"]), h.C, taps=9, upsample=1, bias=pb.const(P[key + ".b"]), qstats=use_qs)
         tn_out = 32 if cfg.out_channels <= 32 else 128
-        if (fuse_gn_out and pb.qstats_ok(h, None, G, h.dom) and pb.gn_fusable(h, None, cfg.out_channels, tile_n=tn_out, out_dt=L.DC_F32)):
+        hn = pb.pn_claim(h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps, True)
+        if hn is not None:      # the last ResNet's conv2 stored conv_norm_out + SiLU of its output: conv_out is a plain thin conv
+            pred = pb.igemm("conv_out", hn, pb.const(P["conv_out.w"]), cfg.out_channels, taps=9, bias=pb.const(P["conv_out.b"]),
+                            out_dt=L.DC_F32, tile_n=tn_out)
+        elif (fuse_gn_out and pb.qstats_ok(h, None, G, h.dom) and pb.gn_fusable(h, None, cfg.out_channels, tile_n=tn_out, out_dt=L.DC_F32)):
             # conv_norm_out + SiLU inside conv_out's halo load (the thin-output conv reads ~1 GB for 3 channels and its VALU is idle):
             # the affine comes from the last conv's quad records, the normalised tensor never exists, one launch instead of two
             aff = pb.groupnorm_stats("conv_norm_out", h, pb.const(P["conv_norm_out.g"]), pb.const(P["conv_norm_out.b"]), G, eps)

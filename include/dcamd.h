@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 /* 2: qstats records are (mean, M2) sets (version 1: sum, sum of squares) and qparts must divide HW
- * 3: dc_ddpm_step_params.one_plus_w; dc_attention requires scale > 0 */
+ * 3: dc_ddpm_step_params.one_plus_w; dc_attention requires scale > 0; dc_igemm_params.pn_* (producer-side GroupNorm) */
 #define DC_ABI_VERSION 3
 
 typedef void* dc_stream; /* hipStream_t */
@@ -129,6 +129,17 @@ typedef struct {
    * cancellation for |mean| >> std): qstats[((n * qparts + part) * (Cout/4) + q) * 2 + (0 = mean | 1 = M2)],
    * qparts = dc_igemm_qstats_parts().  The GroupNorm then streams the tensor once instead of reading it twice.  NULL otherwise. */
   float* qstats;
+  /* producer-side GroupNorm (only where dc_igemm_pn_ok() says so: 3x3 stride-1 conv on power-of-two images of 16x16 ... 64x64, one
+   * source, Cout a multiple of 128): besides — or, with out == NULL, instead of — the raw output v the conv stores
+   *   pn_out[row, co] = act( (v - mean_g) * rstd_g * pn_gamma[co] + pn_beta[co] ),   act = SiLU if pn_silu else identity,
+   * the GroupNorm over pn_groups groups of Cout / pn_groups consecutive channels and all Hout*Wout pixels of the sample (fp32
+   * statistics from the fp32 accumulators, the same (mean, M2) quad records and the same fold dc_groupnorm uses; eps = pn_eps), in
+   * the compute dtype with row stride pn_ld (0: = Cout).  The consumer of that GroupNorm then reads pn_out with a plain conv / GEMM
+   * and the GroupNorm pass over the tensor never runs.  qstats must be given (dc_igemm_qstats_parts() parts per sample: the workgroups
+   * of a sample exchange their records through it); pn_cnt: Hout-independent scratch of n_img * ceil(Cout / 128) uint32 the launch
+   * zeroes itself.  A wait that never completes cannot hang the device: it times out and is counted (dc_pn_timeouts). */
+  void* pn_out; const float* pn_gamma; const float* pn_beta; uint32_t* pn_cnt;
+  int32_t pn_ld, pn_groups, pn_silu; float pn_eps;
 } dc_igemm_params;
 int dc_igemm(const dc_igemm_params* p, dc_stream s);
 int32_t dc_igemm_cout_pad(int32_t cout, int32_t tile_n);
@@ -144,6 +155,11 @@ int32_t dc_igemm_ln_ok(const dc_igemm_params* p);
 /* > 0: dc_igemm can emit qstats for this problem, with that many parts per sample (3x3 halo kernel, output stored in the
  * compute type, Cout a multiple of 8); 0: it cannot. */
 int32_t dc_igemm_qstats_parts(const dc_igemm_params* p);
+/* 1 when dc_igemm can take pn_out / pn_groups (producer-side GroupNorm) for this problem. */
+int32_t dc_igemm_pn_ok(const dc_igemm_params* p);
+/* Number of waves whose wait inside a producer-side-GroupNorm launch timed out since the last call (0 = every launch was sound);
+ * reads and clears a device-side counter: SYNCHRONISES with the device.  Non-zero means results of those launches are invalid. */
+int32_t dc_pn_timeouts(void);
 /* 1 when dc_igemm can take up4 = 1 (four-phase upsample conv) for this problem. */
 int32_t dc_igemm_up4_ok(const dc_igemm_params* p);
 

@@ -842,6 +842,96 @@ def test_wave_specialised_conv_with_fused_groupnorm_is_bit_identical(dt, case):
     assert maxrel(o.float().cpu(), ref.permute(0, 2, 3, 1)) < {L.DC_F32: 3e-5, L.DC_BF16: 1.5e-2, L.DC_F16: 3e-3}[dt]
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("case", ["c128_32x32_res_side_maps", "c256_16x16_one_tile", "c128_64x64_cpg8_raw_dropped", "two_ntiles_32x32_nosilu",
+                                  "c512_16x16_cpg16", "c1024_16x16_cpg32", "c128_32x32_many_samples"])
+def test_conv3x3_normalises_its_own_output_for_the_next_groupnorm(dt, case):
+    """Producer-side GroupNorm (dc_igemm pn_*; csrc/epi_pn.h): the conv stores act(gn(v)) of its output v — the workgroups of a sample
+    exchange their (mean, M2) quad records through memory — next to (or instead of) the raw v.  Checks: the raw output and the quad
+    records equal the plain launch's bit for bit; the normalised output equals dc_groupnorm of those records applied to the fp32
+    values (f32: to rounding noise; 16-bit: within one rounding of the output type, because the producer normalises its fp32
+    accumulators where the GroupNorm kernel reads the rounded tensor) and torch's group_norm + silu; no wait timed out.  One tile per
+    sample (16x16), four (32x32), sixteen (64x64); 4 / 8 / 16 / 32 channels per group; several N tiles; bias, per-sample row
+    vector, residual and 1x1 side source read through sample maps."""
+    torch.manual_seed(77)
+    n, H, W, Ci, Co, groups, side, res, maps, silu, raw = {
+        "c128_32x32_res_side_maps": (7, 32, 32, 128, 128, 32, 128, True, True, True, True),
+        "c256_16x16_one_tile": (6, 16, 16, 128, 256, 32, 0, False, False, True, True),
+        "c128_64x64_cpg8_raw_dropped": (3, 64, 64, 128, 128, 16, 0, True, False, True, False),
+        "two_ntiles_32x32_nosilu": (5, 32, 32, 128, 256, 32, 64, True, False, False, True),
+        "c512_16x16_cpg16": (4, 16, 16, 128, 512, 32, 0, False, False, True, True),
+        "c1024_16x16_cpg32": (2, 16, 16, 64, 1024, 32, 0, False, False, True, False),
+        "c128_32x32_many_samples": (300, 32, 32, 64, 128, 32, 0, False, False, True, True)}[case]
+    q = lambda t: t.to(TD[dt]).float()
+    lib = L.lib()
+    eps = 1e-5 if silu else 1e-6
+    n_src = 3 if maps else n
+    smap = torch.tensor([i % n_src for i in range(n)], dtype=torch.int32, device=DEV) if maps else None
+    x = q(torch.randn(n_src, Ci, H, W))
+    w = q(torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5))
+    b, rv = torch.randn(Co).to(DEV), (torch.randn(n, Co) * 2).to(DEV)
+    a0, Wp = nhwc(x, dt), E.pack_conv3x3(w, dt, DEV)
+    r = torch.randn(n_src if maps else n, H, W, Co, device=DEV).to(TD[dt]) if res else None
+    xs = q(torch.randn(n_src if maps else n, side, H, W)) if side else None
+    ws2 = q(torch.randn(Co, side) / side ** 0.5) if side else None
+    ck = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=Ci, map0=ptr(smap), W=ptr(Wp), Cout=Co,
+              tile_n=128, bias=ptr(b), rowvec=ptr(rv), rowvec_ld=Co, out_dtype=dt, out_ld=Co)
+    keep = []
+    if res:
+        ck.update(residual=ptr(r), res_map=ptr(smap), res_dtype=dt, res_ld=Co)
+    if side:
+        a2, W2 = nhwc(xs, dt), E.pack_matrix(ws2, dt, DEV)
+        keep += [a2, W2]
+        ck.update(src2=ptr(a2), map2=ptr(smap), W2=ptr(W2), C2=side, ld2=side)
+    # the plain launch: raw output + quad records
+    o_ref = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    parts = lib.dc_igemm_qstats_parts(L.IgemmParams(out=ptr(o_ref), **ck))
+    assert parts == H * W // 128
+    q_ref = torch.full((n, parts, Co // 4, 2), float("nan"), device=DEV)
+    run_igemm(out=ptr(o_ref), qstats=ptr(q_ref), **ck)
+    # the GroupNorm kernel on the raw tensor with those records
+    gamma, beta = (torch.randn(Co) * 0.5 + 1).to(DEV), torch.randn(Co).to(DEV)
+    splits = lib.dc_groupnorm_splits(n, H * W, Co)
+    wsb = torch.zeros(lib.dc_groupnorm_ws_floats(n, groups, splits), device=DEV)
+    y_ref = torch.empty_like(o_ref)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(x=ptr(o_ref), y=ptr(y_ref), dtype=dt, out_dtype=dt, n=n, HW=H * W, C=Co, C1=0, groups=groups, silu=int(silu),
+                                               splits=splits, eps=eps, gamma=ptr(gamma), beta=ptr(beta), ws=ptr(wsb), qstats=ptr(q_ref), qparts=parts),
+                             L.stream_ptr()), "gn")
+    # the producer-normalising launch
+    o = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt]) if raw else None
+    y = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    q_o = torch.full((n, parts, Co // 4, 2), float("nan"), device=DEV)
+    cnt = torch.full((n * ((Co + 127) // 128),), 12345, dtype=torch.int32, device=DEV)      # the launch zeroes it itself
+    pp = L.IgemmParams(out=ptr(o), qstats=ptr(q_o), pn_out=ptr(y), pn_gamma=ptr(gamma), pn_beta=ptr(beta), pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=groups,
+                       pn_silu=int(silu), pn_eps=eps, **ck)
+    assert lib.dc_igemm_pn_ok(pp) == 1
+    assert lib.dc_igemm_variant(pp).decode() == "conv3_halo<%s,4w,pn>" % {L.DC_F32: "f32", L.DC_BF16: "bf16", L.DC_F16: "f16"}[dt]
+    for _ in range(2):                                     # twice: the counters are re-armed by every launch
+        L.check(lib.dc_igemm(pp, L.stream_ptr()), "conv with producer-side GroupNorm")
+    torch.cuda.synchronize()
+    assert lib.dc_pn_timeouts() == 0
+    assert torch.equal(cnt, torch.full_like(cnt, H * W // 256))
+    assert torch.equal(q_o, q_ref)
+    if raw:
+        assert torch.equal(o, o_ref)
+    assert torch.isfinite(y.float()).all()
+    # against the GroupNorm kernel: same records, same fold; the 16-bit kernel normalises the ROUNDED tensor, the producer its fp32 values
+    tol_k = {L.DC_F32: 2e-6, L.DC_BF16: 1.6e-2, L.DC_F16: 2e-3}[dt]
+    assert maxrel(y, y_ref) < tol_k, maxrel(y, y_ref)
+    # against torch, from the same rounded operands
+    idx = smap.long().cpu() if maps else torch.arange(n)
+    ref = F.conv2d(x[idx], w, b.cpu(), padding=1) + rv.cpu()[:, :, None, None]
+    if side:
+        ref = ref + torch.einsum("nchw,oc->nohw", xs[idx], ws2)
+    if res:
+        ref = ref + r.float().cpu()[idx].permute(0, 3, 1, 2)
+    yn = F.group_norm(ref, groups, gamma.cpu(), beta.cpu(), eps)
+    if silu:
+        yn = F.silu(yn)
+    assert maxrel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 3e-5, L.DC_BF16: 8e-3, L.DC_F16: 1.5e-3}[dt]
+    assert rel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 1e-5, L.DC_BF16: 4e-3, L.DC_F16: 6e-4}[dt]
+
+
 def test_groupnorm_span_kernel_opt_in():
     """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
     test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
