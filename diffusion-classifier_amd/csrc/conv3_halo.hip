@@ -611,6 +611,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     pc.cnt = a.pn_cnt + (size_t)ng * a.tiles_n + tile_n; pc.timeouts = &g_pn_timeouts;
     pc.gam = brv + 128 + wn * 64 + lq * 8; pc.bet = brv + 256 + wn * 64 + lq * 8;
     pc.scr = reinterpret_cast<float2*>(smem + wave * 4096);
+    pc.flag = reinterpret_cast<int*>(brv + 384);
     pc.eps = a.pn_eps; pc.silu = a.pn_silu;
     epi_halo_pn<T>(a, acc, tile_n, wn, lq, rowfn, brv + wn * 64 + lq * 8, pc);
   } else if constexpr (STAGE_BRV) {

@@ -10,10 +10,11 @@
 // lacks is the rest of its sample: a 256-pixel tile of a 32x32 image sees a quarter of every group.  So the workgroups of one
 // (sample, N tile) exchange their records through memory:
 //
-//   1. every wave writes its (mean, M2) quad records (one 128-pixel part x 16 quads) with agent-scope stores, waits for them,
-//      the workgroup meets at a barrier and ONE lane bumps the arrival counter of the (sample, N tile);
-//   2. every wave polls that counter (agent-scope loads, s_sleep between polls) until all `tiles` workgroups of the sample arrived;
-//   3. every wave copies the sample's records of ITS 64 channels into LDS (one record per lane and trip, all loads in flight
+//   1. every wave writes its (mean, M2) quad records (one 128-pixel part x 16 quads), waits for the stores, the workgroup meets at a
+//      barrier and ONE lane releases at agent scope and bumps the arrival counter of the (sample, N tile);
+//   2. ONE wave polls that counter (relaxed agent-scope loads, s_sleep between polls) until all `tiles` workgroups of the sample
+//      arrived, acquires at agent scope, and the workgroup meets again;
+//   3. every wave copies the sample's records of ITS 64 channels into LDS (two records per lane and trip, all loads in flight
 //      together) and every lane folds the groups of its two 8-channel runs with gn_fold_rec — the GroupNorm kernels' own fold, same
 //      order, same instructions: the affine is bit-identical to what dc_groupnorm / gn_qaffine_kernel form from those records;
 //   4. raw store (if anyone reads the raw tensor), then y = act(v * a + b) in place and the normalised store.
@@ -43,15 +44,11 @@ struct PnCtx {
   unsigned* timeouts;    // library-wide failure counter
   const float* gam;      // LDS: gamma / beta of the lane's run 0 (run k: 32 k floats further)
   const float* bet;
-  float2* scr;           // LDS scratch of this WAVE, parts x 16 records: written only after the workgroup's barrier below
+  float2* scr;           // LDS scratch of this WAVE, parts x 16 records: written only after the workgroup's barriers below
+  int* flag;             // LDS word: the polling wave tells the others whether the wait completed
   float eps;
   int silu;
 };
-
-__device__ __forceinline__ void pn_store_rec(float* p, float x, float y) {
-  const unsigned long long v = ((unsigned long long)__builtin_bit_cast(unsigned, y) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, x);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // acc[i][j]: cout fragment i, pixel fragment j of the wave (128 pixels x 64 couts); brv: bias (+ row vector) of the lane's run 0 in LDS
 template <typename T, typename RowFn>
@@ -152,40 +149,54 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
       }
     if ((threadIdx.x & 15) == 0) {
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        float* p = a.qstats + (((size_t)c.sample * c.parts + c.part) * (a.Cout >> 2) + ((c0 + 32 * k) >> 2)) * 2;
-        pn_store_rec(p, r[k][0], r[k][1]);
-        pn_store_rec(p + 2, r[k][2], r[k][3]);
-      }
+      for (int k = 0; k < NK; ++k)
+        *reinterpret_cast<f32x4*>(a.qstats + (((size_t)c.sample * c.parts + c.part) * (a.Cout >> 2) + ((c0 + 32 * k) >> 2)) * 2) =
+            f32x4{r[k][0], r[k][1], r[k][2], r[k][3]};
     }
   }
-  // ---- 1./2. publish, arrive, wait for the rest of the sample ----
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my records are acknowledged by the memory side
-  __syncthreads();                                           // ... and so are the other waves'; every wave has left the tap loop (LDS is free)
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  bool ok = false;
-  {
+  // ---- 1./2. publish, arrive, wait for the rest of the sample: the release / acquire hand-off of cdna_hip_programming.md Guideline 16
+  // in its counter form (MI355X_MICROARCH.md, inter-workgroup visibility: per-XCD L2s are not coherent, a CU's L1 is never refreshed) —
+  // every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and bumps the counter; ONE wave polls
+  // (relaxed), acquires at agent scope, and the workgroup meets again before anybody loads a record.  A first version with 8-byte
+  // agent-scope atomic stores / loads and no fences passed every single-launch test and handed one sample in a few thousand the
+  // PREVIOUS launch's records when plans were replayed (tests/test_gpu_dist.py caught it).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                           // every wave's records are out; every wave has left the tap loop (LDS is free)
+  bool ok = true;
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop its own wait behind buffer_wbl2: always by hand)
+      __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    ok = false;
     for (;;) {
       const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (seen >= (unsigned)c.tiles) { ok = true; break; }
       if (__builtin_amdgcn_s_memrealtime() - t0 > PN_TIMEOUT_TICKS) break;
       __builtin_amdgcn_s_sleep(8);
     }
-    if (!ok && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      *c.flag = ok ? 1 : 0;
+      if (!ok) __hip_atomic_fetch_add(c.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+  __syncthreads();
+  ok = *c.flag != 0;
   DC_STAMP(6);
-  // ---- 3. the sample's records of this wave's 16 quads -> LDS, then fold the lane's groups ----
+  // ---- 3. the sample's records of this wave's 16 quads -> LDS (two records per lane and trip, every load in flight together), then
+  // fold the lane's groups ----
   {
     const int lane = threadIdx.x & 63;
     const int CQ = a.Cout >> 2;
-    const unsigned long long* recg = reinterpret_cast<const unsigned long long*>(a.qstats) + (size_t)c.sample * c.parts * CQ + ((tile_n * 128 + wn * 64) >> 2);
-    const int nrec = c.parts * 16;
+    const f32x4* recg = reinterpret_cast<const f32x4*>(a.qstats + ((size_t)c.sample * c.parts * CQ + ((tile_n * 128 + wn * 64) >> 2)) * 2);
+    const int npair = c.parts * 8;
 #pragma unroll 4
-    for (int i = lane; i < nrec; i += 64) {
-      const unsigned long long v = __hip_atomic_load(recg + (size_t)(i >> 4) * CQ + (i & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c.scr[i] = float2{__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32))};
-    }
+    for (int i = lane; i < npair; i += 64)
+      *reinterpret_cast<f32x4*>(c.scr + 2 * i) = recg[(size_t)(i >> 3) * (CQ >> 1) + (i & 7)];
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): the wave's own LDS writes (its lanes read each other's records)
   __builtin_amdgcn_wave_barrier();

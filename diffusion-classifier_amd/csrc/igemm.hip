@@ -314,6 +314,11 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
   const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
   // four-phase upsample conv (W in the phase-summed form): the caller opted in, so anything else is an error
+  if (p->up4 && p->pn_out) {      // the four-phase upsample conv does not normalise its own output (its sample spans four phases' workgroups)
+    if (variant) { *variant = "producer-groupnorm-unsupported"; return DC_ERR_UNSUPPORTED; }
+    dc_set_error("dc_igemm: pn_out given with up4 (see dc_igemm_pn_ok)");
+    return DC_ERR_UNSUPPORTED;
+  }
   if (p->up4) {
     const bool up4_halo = bn == 128 && !use_v1 && !no_halo && !a.src1 && dc_conv3_up4_applicable(a, p->dtype) &&
                           (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0 &&

@@ -932,6 +932,47 @@ def test_conv3x3_normalises_its_own_output_for_the_next_groupnorm(dt, case):
     assert rel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 1e-5, L.DC_BF16: 4e-3, L.DC_F16: 6e-4}[dt]
 
 
+def test_producer_normalised_conv_never_reads_a_previous_launch_s_records():
+    """The hand-off inside a producer-normalising conv (csrc/epi_pn.h: records -> agent-scope release -> counter -> acquire -> fold)
+    replayed on the SAME buffers with alternating inputs, as a plan replays it per micro-batch: a wave that folded a record of the
+    previous launch (a stale L2 / L1 line) would store a slightly different tensor.  Every element of every replay must equal the
+    first-touch result of its input; uneven load comes from a second stream streaming a large copy beside half of the replays."""
+    torch.manual_seed(78)
+    dt, n, H, W, Ci, Co = L.DC_BF16, 700, 32, 32, 64, 128
+    lib = L.lib()
+    xs = [nhwc(torch.randn(n, Ci, H, W) * (1.0 + 0.5 * i), dt) for i in range(2)]
+    Wp = E.pack_conv3x3(torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5), dt, DEV)
+    b = torch.randn(Co).to(DEV)
+    gamma, beta = (torch.randn(Co) * 0.5 + 1).to(DEV), torch.randn(Co).to(DEV)
+    parts = H * W // 128
+
+    def launch(x, y, qs, cnt):
+        p = L.IgemmParams(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(x), C0=Ci, W=ptr(Wp), Cout=Co, tile_n=128,
+                          bias=ptr(b), out=None, out_dtype=dt, out_ld=Co, qstats=ptr(qs), pn_out=ptr(y), pn_gamma=ptr(gamma), pn_beta=ptr(beta),
+                          pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=32, pn_silu=1, pn_eps=1e-5)
+        L.check(lib.dc_igemm(p, L.stream_ptr()), "pn conv")
+    want = []
+    for x in xs:                               # first touch: fresh buffers
+        y, qs, cnt = torch.empty(n, H, W, Co, dtype=TD[dt], device=DEV), torch.zeros(n, parts, Co // 4, 2, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV)
+        launch(x, y, qs, cnt)
+        torch.cuda.synchronize()
+        want.append(y)
+    assert not torch.equal(want[0], want[1])
+    y, qs, cnt = torch.empty_like(want[0]), torch.zeros(n, parts, Co // 4, 2, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV)
+    big_a, big_b = torch.empty(1 << 28, dtype=torch.uint8, device=DEV), torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    bad = 0
+    for it in range(24):
+        if it % 4 >= 2:
+            with torch.cuda.stream(side):
+                big_b.copy_(big_a)
+        launch(xs[it & 1], y, qs, cnt)
+        bad += int((y != want[it & 1]).sum().item())
+    torch.cuda.synchronize()
+    assert lib.dc_pn_timeouts() == 0
+    assert bad == 0, bad
+
+
 def test_groupnorm_span_kernel_opt_in():
     """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
     test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
