@@ -886,8 +886,6 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
       static bool pn_attr = false;
       kern = conv3_halo_kernel<T, 4, 9, 1, false, true>;
       if (!pn_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS); pn_attr = true; }
-      // arrival counters, one per (sample, N tile): zeroed on the stream in front of every launch
-      if (hipMemsetAsync(a.pn_cnt, 0, (size_t)n_img * a.tiles_n * sizeof(unsigned), s) != hipSuccess) { dc_set_error("conv3_halo: counter memset failed"); return DC_ERR_LAUNCH; }
     } else {
       dc_set_error("conv3_halo: producer-side GroupNorm needs images of at least 16x16"); return DC_ERR_SHAPE;
     }

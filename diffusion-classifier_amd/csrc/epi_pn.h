@@ -40,7 +40,7 @@ struct PnCtx {
   int parts;             // parts per sample (HW / 128)
   int tiles;             // workgroups per (sample, N tile) = HW / 256
   int qpg;               // quads per GroupNorm group (channels per group / 4): 1, 2, 4 or 8
-  unsigned* cnt;         // arrival counter of this (sample, N tile); zeroed by the launch
+  unsigned* cnt;         // arrival counter of this (sample, N tile): monotonic, zeroed ONCE by the caller, never reset
   unsigned* timeouts;    // library-wide failure counter
   const float* gam;      // LDS: gamma / beta of the lane's run 0 (run k: 32 k floats further)
   const float* bet;
@@ -164,16 +164,23 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
   __syncthreads();                                           // every wave's records are out; every wave has left the tap loop (LDS is free)
   bool ok = true;
   if (threadIdx.x < 64) {
+    // The counter is never reset: every launch adds exactly `tiles` arrivals to it, so the ticket my add returns says which launch
+    // this is, and the target is the next multiple of `tiles` above the ticket.  (A counter zeroed per launch let a poller that was
+    // served an OLD value of the line — the previous replay's final count — pass before its peers had arrived, and fold the previous
+    // replay's records: one sample of a 3-sample launch, 3e-4 off.  A stale value of a monotonic counter is only ever too small.)
+    unsigned ticket = 0;
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop its own wait behind buffer_wbl2: always by hand)
-      __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    const unsigned target = (ticket & ~(unsigned)(c.tiles - 1)) + (unsigned)c.tiles;          // tiles is a power of two
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     ok = false;
     for (;;) {
       const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (seen >= (unsigned)c.tiles) { ok = true; break; }
+      if ((int)(seen - target) >= 0) { ok = true; break; }
       if (__builtin_amdgcn_s_memrealtime() - t0 > PN_TIMEOUT_TICKS) break;
       __builtin_amdgcn_s_sleep(8);
     }

@@ -106,15 +106,21 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     // a wave's pixels normally lie inside one image)
     const bool uni = samp_first == samp_last;
     prefn();      // the caller's own waits (igemm_xreg drains its LDS-DMA here) overlap the bias loads issued above
-    if (!BiasFn::has_rowvec && !geglu && a.rowvec && uni) {
+    // The row vector is added AFTER the bias in every branch — (acc + bias) + rowvec — also when the whole wave shares one sample and
+    // one fetch serves it.  Rounds 1-3 pre-summed bias + rowvec in that case: acc + (bias + rowvec) differs from the per-pixel
+    // branches in the last fp32 bit, and which branch a sample meets depends on where it sits in the launch (the LAST sample of a
+    // launch is alone in its wave where it otherwise shares one): the quad statistics of an 8x8-level conv then depended on the
+    // micro-batch size (round 4: tests/test_gpu_dist.py, world size 3 against 1).
+    const bool rv_uni = !BiasFn::has_rowvec && !geglu && a.rowvec && uni;
+    float rvu[NK][8];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rvu[k][e] = 0.f;
+    if (rv_uni) {
 #pragma unroll
       for (int k = 0; k < NK; ++k)
-        if (con[k]) {
-          float rv[8];
-          ld8(a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[samp_first] : samp_first) * a.rowvec_ld + c0 + 32 * k, rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bs[k][e] += rv[e];
-        }
+        if (con[k]) ld8(a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[samp_first] : samp_first) * a.rowvec_ld + c0 + 32 * k, rvu[k]);
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j)
@@ -126,6 +132,14 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
           for (int k = 0; k < NK; ++k) acc[2 * k + (e >> 2)][j][e & 3] += bs[k][e];
         }
       }
+    if (rv_uni) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int k = 0; k < NK; ++k) acc[2 * k + (e >> 2)][j][e & 3] += rvu[k][e];
+    }
     if (!BiasFn::has_rowvec && !geglu && a.rowvec && !uni) {
       if (TWO_SAMP) {
         // the wave's pixels belong to samp_first or samp_last only (images at least as large as the wave's pixel range:

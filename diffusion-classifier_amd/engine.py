@@ -199,9 +199,9 @@ class PlanBuilder:
             return None
         dom = x.dom
         y = self.tensor(x.name + ".pn", dom, x.H, x.W, x.C, x.dt)
-        cnt = TRef(x.name + ".pncnt", dom, 1, 1, 1, L.DC_F32, nbytes=round_up(self.n[dom] * ((f["Cout"] + 127) // 128) * 4, 256))
-        for t in (y, cnt):
-            t.first = t.last = idx
+        # arrival counters of this call site: monotonic, zeroed once here, never part of the (reused) arena
+        cnt = self.const(torch.zeros(self.n[dom] * ((f["Cout"] + 127) // 128), dtype=torch.int32, device=self.dev))
+        y.first = y.last = idx
         f.update(pn_out=y, pn_gamma=gamma, pn_beta=beta, pn_cnt=cnt, pn_ld=y.ld, pn_groups=groups, pn_silu=int(silu), pn_eps=float(eps))
         self.meta[idx]["bytes"] += float(self.n[dom] * x.H * x.W * x.C * DT_SIZE[x.dt])
         self.meta[idx]["pn"] = True

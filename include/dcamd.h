@@ -136,8 +136,9 @@ typedef struct {
    * statistics from the fp32 accumulators, the same (mean, M2) quad records and the same fold dc_groupnorm uses; eps = pn_eps), in
    * the compute dtype with row stride pn_ld (0: = Cout).  The consumer of that GroupNorm then reads pn_out with a plain conv / GEMM
    * and the GroupNorm pass over the tensor never runs.  qstats must be given (dc_igemm_qstats_parts() parts per sample: the workgroups
-   * of a sample exchange their records through it); pn_cnt: Hout-independent scratch of n_img * ceil(Cout / 128) uint32 the launch
-   * zeroes itself.  A wait that never completes cannot hang the device: it times out and is counted (dc_pn_timeouts). */
+   * of a sample exchange their records through it); pn_cnt: n_img * ceil(Cout / 128) uint32 arrival counters that belong to THIS
+   * call site: zeroed once by the caller, then left alone — they only ever grow (every launch adds Hout*Wout/256 to each), which is
+   * what makes a stale read of one harmless.  A wait that never completes cannot hang the device: it times out and is counted (dc_pn_timeouts). */
   void* pn_out; const float* pn_gamma; const float* pn_beta; uint32_t* pn_cnt;
   int32_t pn_ld, pn_groups, pn_silu; float pn_eps;
 } dc_igemm_params;

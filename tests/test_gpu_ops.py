@@ -901,16 +901,16 @@ def test_conv3x3_normalises_its_own_output_for_the_next_groupnorm(dt, case):
     o = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt]) if raw else None
     y = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
     q_o = torch.full((n, parts, Co // 4, 2), float("nan"), device=DEV)
-    cnt = torch.full((n * ((Co + 127) // 128),), 12345, dtype=torch.int32, device=DEV)      # the launch zeroes it itself
+    cnt = torch.zeros(n * ((Co + 127) // 128), dtype=torch.int32, device=DEV)      # zeroed ONCE: the counters are monotonic
     pp = L.IgemmParams(out=ptr(o), qstats=ptr(q_o), pn_out=ptr(y), pn_gamma=ptr(gamma), pn_beta=ptr(beta), pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=groups,
                        pn_silu=int(silu), pn_eps=eps, **ck)
     assert lib.dc_igemm_pn_ok(pp) == 1
     assert lib.dc_igemm_variant(pp).decode() == "conv3_halo<%s,4w,pn>" % {L.DC_F32: "f32", L.DC_BF16: "bf16", L.DC_F16: "f16"}[dt]
-    for _ in range(2):                                     # twice: the counters are re-armed by every launch
+    for _ in range(2):                                     # twice: nothing is reset between launches
         L.check(lib.dc_igemm(pp, L.stream_ptr()), "conv with producer-side GroupNorm")
     torch.cuda.synchronize()
     assert lib.dc_pn_timeouts() == 0
-    assert torch.equal(cnt, torch.full_like(cnt, H * W // 256))
+    assert torch.equal(cnt, torch.full_like(cnt, 2 * (H * W // 256)))
     assert torch.equal(q_o, q_ref)
     if raw:
         assert torch.equal(o, o_ref)
@@ -932,13 +932,15 @@ def test_conv3x3_normalises_its_own_output_for_the_next_groupnorm(dt, case):
     assert rel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 1e-5, L.DC_BF16: 4e-3, L.DC_F16: 6e-4}[dt]
 
 
-def test_producer_normalised_conv_never_reads_a_previous_launch_s_records():
+@pytest.mark.parametrize("n", [700, 3])
+def test_producer_normalised_conv_never_reads_a_previous_launch_s_records(n):
     """The hand-off inside a producer-normalising conv (csrc/epi_pn.h: records -> agent-scope release -> counter -> acquire -> fold)
     replayed on the SAME buffers with alternating inputs, as a plan replays it per micro-batch: a wave that folded a record of the
     previous launch (a stale L2 / L1 line) would store a slightly different tensor.  Every element of every replay must equal the
-    first-touch result of its input; uneven load comes from a second stream streaming a large copy beside half of the replays."""
+    first-touch result of its input; uneven load comes from a second stream streaming a large copy beside half of the replays.  n = 3 is the
+    case that failed once (round 4): so little traffic that the previous replay's lines survive in L2 between launches."""
     torch.manual_seed(78)
-    dt, n, H, W, Ci, Co = L.DC_BF16, 700, 32, 32, 64, 128
+    dt, H, W, Ci, Co = L.DC_BF16, 32, 32, 64, 128
     lib = L.lib()
     xs = [nhwc(torch.randn(n, Ci, H, W) * (1.0 + 0.5 * i), dt) for i in range(2)]
     Wp = E.pack_conv3x3(torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5), dt, DEV)
