@@ -610,7 +610,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     pc.qpg = (a.Cout / a.pn_groups) >> 2;
     pc.cnt = a.pn_cnt + (size_t)ng * a.tiles_n + tile_n; pc.timeouts = &g_pn_timeouts;
     pc.gam = brv + 128 + wn * 64 + lq * 8; pc.bet = brv + 256 + wn * 64 + lq * 8;
-    pc.scr = reinterpret_cast<float2*>(smem + wave * 4096);
+    // records of the wave's 64 channels: a sample of several tiles -> per wave (<= 32 parts x 128 B); one tile -> the two parts meet in an
+    // area shared by the two waves of the N half
+    pc.scr = reinterpret_cast<float2*>(g.lpt ? smem + wave * 4096 : smem + wn * 256);
     pc.flag = reinterpret_cast<int*>(brv + 384);
     pc.eps = a.pn_eps; pc.silu = a.pn_silu;
     epi_halo_pn<T>(a, acc, tile_n, wn, lq, rowfn, brv + wn * 64 + lq * 8, pc);

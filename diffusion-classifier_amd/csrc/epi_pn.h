@@ -10,12 +10,12 @@
 // lacks is the rest of its sample: a 256-pixel tile of a 32x32 image sees a quarter of every group.  So the workgroups of one
 // (sample, N tile) exchange their records through memory:
 //
-//   1. every wave writes its (mean, M2) quad records (one 128-pixel part x 16 quads), waits for the stores, the workgroup meets at a
-//      barrier and ONE lane releases at agent scope and bumps the arrival counter of the (sample, N tile);
+//   1. every wave writes its (mean, M2) quad records (one 128-pixel part x 16 quads = one 128-byte line) with ONE write-through
+//      store instruction, waits for it, the workgroup meets at a barrier and ONE lane bumps the arrival counter of the (sample, N tile);
 //   2. ONE wave polls that counter (relaxed agent-scope loads, s_sleep between polls) until all `tiles` workgroups of the sample
-//      arrived, acquires at agent scope, and the workgroup meets again;
-//   3. every wave copies the sample's records of ITS 64 channels into LDS (two records per lane and trip, all loads in flight
-//      together) and every lane folds the groups of its two 8-channel runs with gn_fold_rec — the GroupNorm kernels' own fold, same
+//      arrived, and the workgroup meets again;
+//   3. every wave copies the sample's records of ITS 64 channels into LDS (16-byte `sc1` loads, two records per lane and load, all
+//      loads in flight together) and every lane folds the groups of its two 8-channel runs with gn_fold_rec — the GroupNorm kernels' own fold, same
 //      order, same instructions: the affine is bit-identical to what dc_groupnorm / gn_qaffine_kernel form from those records;
 //   4. raw store (if anyone reads the raw tensor), then y = act(v * a + b) in place and the normalised store.
 //
@@ -44,7 +44,8 @@ struct PnCtx {
   unsigned* timeouts;    // library-wide failure counter
   const float* gam;      // LDS: gamma / beta of the lane's run 0 (run k: 32 k floats further)
   const float* bet;
-  float2* scr;           // LDS scratch of this WAVE, parts x 16 records: written only after the workgroup's barriers below
+  float2* scr;           // LDS scratch, parts x 16 records of the wave's 64 channels, written only after the workgroup's barrier below: per
+                         // WAVE when the sample spans several tiles, shared by the two waves of an N half when it is one tile
   int* flag;             // LDS word: the polling wave tells the others whether the wait completed
   float eps;
   int silu;
@@ -103,6 +104,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
     }
   }
   DC_STAMP(5);
+  f32x4 rec;
   // ---- quad statistics of the wave's part: the arithmetic of igemm_epilogue.h's `emit` (whole-wave form), so that the records
   // are the ones a plain conv3_halo launch writes into IgemmArgs::qstats ----
   {
@@ -147,63 +149,78 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
         r[k][2 * qd] = __builtin_fmaf(S, inv_n, piv[k][qd]);
         r[k][2 * qd + 1] = fmaxf(__builtin_fmaf(-S * S, inv_n, Q), 0.f);
       }
-    if ((threadIdx.x & 15) == 0) {
-#pragma unroll
-      for (int k = 0; k < NK; ++k)
-        *reinterpret_cast<f32x4*>(a.qstats + (((size_t)c.sample * c.parts + c.part) * (a.Cout >> 2) + ((c0 + 32 * k) >> 2)) * 2) =
-            f32x4{r[k][0], r[k][1], r[k][2], r[k][3]};
-    }
+    // every lane of a 16-lane row holds the row's records (the DPP butterflies leave the totals everywhere): lane lr = 0 publishes run
+    // 0's pair of quads, lane lr = 1 run 1's — ONE 16-byte store instruction of the wave writes its whole 128-byte record line
+    const int lr = threadIdx.x & 15;
+    rec = lr == 0 ? f32x4{r[0][0], r[0][1], r[0][2], r[0][3]} : f32x4{r[1][0], r[1][1], r[1][2], r[1][3]};
   }
-  // ---- 1./2. publish, arrive, wait for the rest of the sample: the release / acquire hand-off of cdna_hip_programming.md Guideline 16
-  // in its counter form (MI355X_MICROARCH.md, inter-workgroup visibility: per-XCD L2s are not coherent, a CU's L1 is never refreshed) —
-  // every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and bumps the counter; ONE wave polls
-  // (relaxed), acquires at agent scope, and the workgroup meets again before anybody loads a record.  A first version with 8-byte
-  // agent-scope atomic stores / loads and no fences passed every single-launch test and handed one sample in a few thousand the
-  // PREVIOUS launch's records when plans were replayed (tests/test_gpu_dist.py caught it).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                           // every wave's records are out; every wave has left the tap loop (LDS is free)
+  const int lrp = threadIdx.x & 15;
+  const int qpub = 2 * lq + 8 * (lrp & 1);                   // first quad (among the wave's 16) of the pair this lane publishes
+  float* const grec = a.qstats + (((size_t)c.sample * c.parts + c.part) * (a.Cout >> 2) + ((tile_n * 128 + wn * 64) >> 2) + qpub) * 2;
   bool ok = true;
-  if (threadIdx.x < 64) {
-    // The counter is never reset: every launch adds exactly `tiles` arrivals to it, so the ticket my add returns says which launch
-    // this is, and the target is the next multiple of `tiles` above the ticket.  (A counter zeroed per launch let a poller that was
-    // served an OLD value of the line — the previous replay's final count — pass before its peers had arrived, and fold the previous
-    // replay's records: one sample of a 3-sample launch, 3e-4 off.  A stale value of a monotonic counter is only ever too small.)
-    unsigned ticket = 0;
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop its own wait behind buffer_wbl2: always by hand)
-      ticket = __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    const unsigned target = (ticket & ~(unsigned)(c.tiles - 1)) + (unsigned)c.tiles;          // tiles is a power of two
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    ok = false;
-    for (;;) {
-      const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if ((int)(seen - target) >= 0) { ok = true; break; }
-      if (__builtin_amdgcn_s_memrealtime() - t0 > PN_TIMEOUT_TICKS) break;
-      __builtin_amdgcn_s_sleep(8);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (c.tiles == 1) {
+    // ---- the whole sample is this workgroup's tile (16x16 images): the two parts meet in LDS, nothing crosses a workgroup.  The records
+    // still go to memory (plain stores) for any OTHER GroupNorm that reads this tensor's statistics later.
+    if (lrp < 2) *reinterpret_cast<f32x4*>(grec) = rec;
+    __syncthreads();                                         // every wave has left the tap loop: the scratch (a halo buffer) is free
+    if (lrp < 2) *reinterpret_cast<f32x4*>(c.scr + c.part * 16 + qpub) = rec;
+    __syncthreads();
+  } else {
+    // ---- 1./2. publish, arrive, wait for the rest of the sample.  The hand-off is the counter form measured in MI355X_MICROARCH.md
+    // (inter-workgroup visibility, third row of the table of `sc1` hand-offs): every record line is written whole by ONE `sc1`
+    // (write-through) 16-byte store instruction of one wave; every storing wave drains its stores (vmcnt 0); the workgroup meets; ONE
+    // lane adds to the agent-scope counter; ONE wave polls it with `sc1` loads; the workgroup meets again; every record is then
+    // loaded with a 16-byte `sc1` load.  No L2 write-back, no cache invalidate: a fence pair cost this epilogue 30 % of the conv.
+    // The counter is never reset: every launch adds exactly `tiles` arrivals, the ticket my add returns tells which launch this is, and
+    // the target is the next multiple of `tiles` above it — an old value of the counter line can only be too small.
+    if (lrp < 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(grec), "v"(rec) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
-      *c.flag = ok ? 1 : 0;
-      if (!ok) __hip_atomic_fetch_add(c.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                         // every wave's records are out; every wave has left the tap loop (LDS is free)
+    if (threadIdx.x < 64) {
+      unsigned ticket = 0;
+      if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      const unsigned target = (ticket & ~(unsigned)(c.tiles - 1)) + (unsigned)c.tiles;        // tiles is a power of two
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      ok = false;
+      for (;;) {
+        const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if ((int)(seen - target) >= 0) { ok = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > PN_TIMEOUT_TICKS) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (threadIdx.x == 0) {
+        *c.flag = ok ? 1 : 0;
+        if (!ok) __hip_atomic_fetch_add(c.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-  }
-  __syncthreads();
-  ok = *c.flag != 0;
-  DC_STAMP(6);
-  // ---- 3. the sample's records of this wave's 16 quads -> LDS (two records per lane and trip, every load in flight together), then
-  // fold the lane's groups ----
-  {
-    const int lane = threadIdx.x & 63;
-    const int CQ = a.Cout >> 2;
-    const f32x4* recg = reinterpret_cast<const f32x4*>(a.qstats + ((size_t)c.sample * c.parts * CQ + ((tile_n * 128 + wn * 64) >> 2)) * 2);
-    const int npair = c.parts * 8;
-#pragma unroll 4
-    for (int i = lane; i < npair; i += 64)
-      *reinterpret_cast<f32x4*>(c.scr + 2 * i) = recg[(size_t)(i >> 3) * (CQ >> 1) + (i & 7)];
+    __syncthreads();
+    ok = *c.flag != 0;
+    DC_STAMP(6);
+    // ---- 3. the sample's records of this wave's 16 quads -> LDS: two records per lane and load, at most four loads per lane (32 parts),
+    // all in flight together
+    {
+      const int lane = threadIdx.x & 63;
+      const int CQ = a.Cout >> 2;
+      const float* recs = a.qstats + ((size_t)c.sample * c.parts * CQ + ((tile_n * 128 + wn * 64) >> 2)) * 2;
+      const int npair = c.parts * 8;
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = lane + 64 * u;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < npair) {
+          const float* p = recs + ((size_t)(i >> 3) * CQ + 2 * (i & 7)) * 2;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u]) : "v"(p) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = lane + 64 * u;
+        if (i < npair) *reinterpret_cast<f32x4*>(c.scr + 2 * i) = v[u];
+      }
+    }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): the wave's own LDS writes (its lanes read each other's records)
   __builtin_amdgcn_wave_barrier();

@@ -181,6 +181,16 @@ class PlanBuilder:
             out.prod = len(self.ops) - 1
         return out
 
+    def pn_capable(self, x, Cout, dom):
+        """Would a plain 3x3 stride-1 conv of x (single source) be able to normalise its own output (dc_igemm_pn_ok)?"""
+        if self.pn_off or L.lib().dc_igemm_pn_ok is None or Cout % 32:
+            return False
+        fake = 1 << 20
+        p = L.IgemmParams(dtype=x.dt, taps=9, stride=1, upsample=0, n_img=self.n[dom], Hin=x.H, Win=x.W, Hout=x.H, Wout=x.W,
+                          src0=fake, C0=x.C, ld0=x.ld, W=fake, Cout=Cout, tile_n=128, out=fake, out_dtype=x.dt, out_ld=Cout,
+                          pn_groups=32, pn_eps=1e-5)
+        return bool(L.lib().dc_igemm_pn_ok(p))
+
     def pn_claim(self, x, gamma, beta, groups, eps, silu):
         """Producer-side GroupNorm (dc_igemm_params.pn_*; csrc/epi_pn.h): ask the 3x3 conv that produced x to ALSO store
         act(GroupNorm(x)) — its accumulators hold every value in fp32 and it writes the statistics anyway — so that the consumer of
@@ -759,7 +769,11 @@ class UNetPlan:
             y = pb.pn_claim(x, gamma, beta, groups, eps, True)
             if y is not None:
                 return pb.igemm(cname, y, Wp, Cout, taps=9, **kw)
-            if fuse_ws and dom == x.dom and pb.qstats_ok(x, None, groups, dom) and pb.gn_ws_ok(x, Cout):
+            # second: where this conv could in turn normalise its own output for the NEXT GroupNorm, keep it the plain halo conv behind a
+            # GroupNorm pass (one pass at the head of a chain of producer-normalised convs) rather than the wave-specialised conv, whose
+            # epilogue cannot (conv3_ws.hip: one workgroup per CU, 0.75 against 1.0 PF)
+            chain = kw.get("qstats") and pb.pn_capable(x, Cout, dom)
+            if not chain and fuse_ws and dom == x.dom and pb.qstats_ok(x, None, groups, dom) and pb.gn_ws_ok(x, Cout):
                 aff = pb.groupnorm_stats(gname, x, gamma, beta, groups, eps)
                 return pb.igemm(cname, x, Wp, Cout, taps=9, gn=(aff[0], aff[1], True), **kw)
             y = pb.groupnorm(gname, x, gamma, beta, groups, eps, True)
