@@ -57,6 +57,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
                                             const float* brv, const PnCtx& c) {
   constexpr int TM = 8, NK = 2;
   constexpr bool res16 = sizeof(T) == 2;
+  const int abl = DC_HALO_ABL();                             // 0 outside diagnostic builds (timing-only ablations: 16 no wait, 32 no SiLU)
   const int c0 = tile_n * 128 + wn * 64 + lq * 8;            // run k starts at c0 + 32 k (Cout is a multiple of 128: every run is real)
   // ---- A1: bias + row vector (staged in LDS at kernel start) ----
 #pragma unroll
@@ -65,7 +66,6 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
 #pragma unroll
     for (int j = 0; j < TM; ++j) { acc[2 * k][j] += lo; acc[2 * k + 1][j] += hi; }
   }
-  DC_STAMP(3);
   // ---- A2: residual, every load of the wave in front of every store (vmcnt is one in-order counter) ----
   int orow[TM];
   {
@@ -80,7 +80,6 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
 #pragma unroll
           for (int k = 0; k < NK; ++k)
             rc[j][k] = *reinterpret_cast<const chunk16*>(reinterpret_cast<const char*>(a.residual) + ((size_t)row[j].r * a.res_ld + c0 + 32 * k) * 2);
-        DC_STAMP(4);
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -103,7 +102,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
       }
     }
   }
-  DC_STAMP(5);
+  DC_STAMP(3);
   f32x4 rec;
   // ---- quad statistics of the wave's part: the arithmetic of igemm_epilogue.h's `emit` (whole-wave form), so that the records
   // are the ones a plain conv3_halo launch writes into IgemmArgs::qstats ----
@@ -176,6 +175,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
     if (lrp < 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(grec), "v"(rec) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                         // every wave's records are out; every wave has left the tap loop (LDS is free)
+    DC_STAMP(4);
     if (threadIdx.x < 64) {
       unsigned ticket = 0;
       if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -185,7 +185,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
       ok = false;
       for (;;) {
         const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if ((int)(seen - target) >= 0) { ok = true; break; }
+        if ((int)(seen - target) >= 0 || (abl & 16)) { ok = true; break; }
         if (__builtin_amdgcn_s_memrealtime() - t0 > PN_TIMEOUT_TICKS) break;
         __builtin_amdgcn_s_sleep(4);
       }
@@ -196,7 +196,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
     }
     __syncthreads();
     ok = *c.flag != 0;
-    DC_STAMP(6);
+    DC_STAMP(5);
     // ---- 3. the sample's records of this wave's 16 quads -> LDS: two records per lane and load, at most four loads per lane (32 parts),
     // all in flight together
     {
@@ -252,6 +252,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
       }
     }
   }
+  DC_STAMP(6);
   // ---- 4. stores: raw (if it has a reader), then the normalised tensor ----
   if (a.out) {
     if (a.out_dtype == DC_F32) {
@@ -274,23 +275,29 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
         }
     }
   }
+  // (the activation switch sits OUTSIDE the unrolled loops: a taken scalar branch per element costs ~20 cycles on this core)
+  auto store_norm = [&](auto actc) {
+    constexpr bool ACT = decltype(actc)::value;
 #pragma unroll
-  for (int j = 0; j < TM; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      float v[8];
+      for (int k = 0; k < NK; ++k) {
+        float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = acc[2 * k + (e >> 2)][j][e & 3] * ga[k][e] + gb[k][e];
-        if (c.silu) x = silu_t<T>(x);
-        v[e] = x;
+        for (int e = 0; e < 8; ++e) {
+          float x = acc[2 * k + (e >> 2)][j][e & 3] * ga[k][e] + gb[k][e];
+          if (ACT) x = silu_t<T>(x);
+          v[e] = x;
+        }
+        T* op = reinterpret_cast<T*>(a.pn_out) + (size_t)orow[j] * a.pn_ld + c0 + 32 * k;
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          *reinterpret_cast<chunk16*>(op) = f_to_chunk<T>(v);
+        }
       }
-      T* op = reinterpret_cast<T*>(a.pn_out) + (size_t)orow[j] * a.pn_ld + c0 + 32 * k;
-      if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else {
-        *reinterpret_cast<chunk16*>(op) = f_to_chunk<T>(v);
-      }
-    }
+  };
+  if (c.silu && !(abl & 32)) store_norm(EpiIC<1>{});
+  else store_norm(EpiIC<0>{});
 }

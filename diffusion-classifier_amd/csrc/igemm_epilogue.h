@@ -17,6 +17,9 @@
 #ifndef DC_STAMP
 #define DC_STAMP(k) do {} while (0)   // conv3_halo.hip defines the diagnostic version (-DDC_STAMPS builds only)
 #endif
+#ifndef DC_HALO_ABL
+#define DC_HALO_ABL() 0               // timing-only ablation switches of diagnostic builds (conv3_halo.hip)
+#endif
 
 // LDS row R (0..127) of the weight tile -> packed weight row of the N tile that must be loaded there
 __device__ __forceinline__ int epi_wrow(int R, bool geglu) {

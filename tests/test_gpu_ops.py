@@ -910,7 +910,7 @@ def test_conv3x3_normalises_its_own_output_for_the_next_groupnorm(dt, case):
         L.check(lib.dc_igemm(pp, L.stream_ptr()), "conv with producer-side GroupNorm")
     torch.cuda.synchronize()
     assert lib.dc_pn_timeouts() == 0
-    assert torch.equal(cnt, torch.full_like(cnt, 2 * (H * W // 256)))
+    assert torch.equal(cnt, torch.full_like(cnt, 2 * (H * W // 256) if H * W > 256 else 0))     # (one tile per sample: nothing crosses a workgroup)
     assert torch.equal(q_o, q_ref)
     if raw:
         assert torch.equal(o, o_ref)
