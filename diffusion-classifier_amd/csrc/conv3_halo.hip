@@ -91,11 +91,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int wm = wave >> 1, wn = wave & 1;      // NW/2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
-  if constexpr (PN) {      // group-major: block b = ((sample * tiles_n + N tile) << lpt) + tile of the image
-    const int grp = blockIdx.x >> g.lpt;
+  if constexpr (PN) {
+    // The workgroups that share a sample's statistics — a group: (sample, N tile) x the 2^lpt tiles of the image — sit on CONSECUTIVE
+    // positions of ONE XCD's dispatch queue: blocks are dealt round-robin to the 8 XCDs (b and b + 8 share one), so position k = b >> 3
+    // of queue b & 7 is tile k & (2^lpt - 1) of that queue's group k >> lpt, and the groups are dealt round-robin to the queues.  The
+    // grid is padded to a multiple of 8 groups; the surplus workgroups leave at once.  (With the groups on consecutive BLOCK indices
+    // instead, their members sat in different queues, the queues drifted apart, and a 16-tile group waited 30 k cycles of a 60 k-cycle
+    // tile for its slowest member — stamps, tools/stamp_pn.py; correctness never depends on the placement, see epi_pn.h.)
+    const int kq = blockIdx.x >> 3;
+    const int grp = ((kq >> g.lpt) << 3) + (blockIdx.x & 7);
+    if (grp >= g.n_img * a.tiles_n) return;
     const int smp = grp / a.tiles_n;
     tile_n = __builtin_amdgcn_readfirstlane(grp - smp * a.tiles_n);
-    tile_m = __builtin_amdgcn_readfirstlane((smp << g.lpt) + (blockIdx.x & ((1 << g.lpt) - 1)));
+    tile_m = __builtin_amdgcn_readfirstlane((smp << g.lpt) + (kq & ((1 << g.lpt) - 1)));
     asm volatile("" : "+s"(tile_m), "+s"(tile_n));
   } else if constexpr (XB) tile_of_block_scalar(a, tile_m, tile_n);     // buffer-descriptor loaders: scalar offsets must be SGPRs (no waterfall loops)
   else tile_of_block(a, tile_m, tile_n);
@@ -910,7 +918,13 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
       }
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS, s, a, g);
+  long long grid = nblk;
+  if (a.pn_out) {          // whole groups of 2^lpt workgroups, a multiple of 8 of them (PN block order, see the kernel)
+    const long long groups = (long long)n_img * a.tiles_n;
+    grid = ((groups + 7) / 8 * 8) << g.lpt;
+    if (grid > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", grid); return DC_ERR_SHAPE; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS, s, a, g);
   return dc_check_launch("dc_igemm(conv3_halo)");
 }
 

@@ -15,14 +15,15 @@
 //   2. ONE wave polls that counter (relaxed agent-scope loads, s_sleep between polls) until all `tiles` workgroups of the sample
 //      arrived, and the workgroup meets again;
 //   3. every wave copies the sample's records of ITS 64 channels into LDS (16-byte `sc1` loads, two records per lane and load, all
-//      loads in flight together) and every lane folds the groups of its two 8-channel runs with gn_fold_rec — the GroupNorm kernels' own fold, same
-//      order, same instructions: the affine is bit-identical to what dc_groupnorm / gn_qaffine_kernel form from those records;
+//      loads in flight together) and the 16 lanes of a row fold the groups of their two 8-channel runs together (pn_fold_row: the GroupNorm
+//      kernels' shifted one-pass form over the same records, the parts dealt to the lanes);
 //   4. raw store (if anyone reads the raw tensor), then y = act(v * a + b) in place and the normalised store.
 //
-// Forward progress: a workgroup waits only for workgroups of its own (sample, N tile), which the launch places on CONSECUTIVE
-// block indices (conv3_halo.hip, PN tile order).  Workgroups are dispatched in index order, so when one member of a group is
-// resident every earlier group is resident or finished, and the members not yet dispatched are next in line: they start as soon
-// as ANY resident workgroup of an earlier, complete group retires — which those can always do.  The host refuses groups larger
+// Forward progress: a workgroup waits only for workgroups of its own (sample, N tile), which the launch places on consecutive
+// positions of one XCD's dispatch queue (conv3_halo.hip, PN block order).  Workgroups are dispatched in index order, so when one member
+// of a group is resident every earlier group of that queue is resident or finished, and the members not yet dispatched are next in
+// line: they start as soon as ANY resident workgroup of an earlier, complete group retires — which those can always do.  (If the
+// hardware dealt blocks to XCDs in another way the members would merely sit further apart in the one global order; same argument.)  The host refuses groups larger
 // than a fraction of the chip's workgroup slots (dc_igemm_pn_ok).  The poll loop is bounded all the same (PN_TIMEOUT_TICKS of the
 // 100 MHz real-time counter): a wave that times out raises g_pn_timeouts (checked by the host, dc_pn_timeouts) and goes on with
 // whatever records are there — wrong numbers and an error, never a hang.
@@ -50,6 +51,35 @@ struct PnCtx {
   float eps;
   int silu;
 };
+
+// Fold the records of one GroupNorm group — local quads [q0, q0 + qpg) of every part, in scr[part * 16 + quad] — with the 16 lanes of a
+// row sharing the parts (lane lr takes parts lr, lr + 16, ...): equal counts, means shifted by the first record's (gn_fold_rec's form:
+// mean = piv + S1 / R, M2 = S2 + nq (S3 - S1^2 / R)), lane partials joined by the DPP butterfly, so every lane of the row ends with the
+// same bits.  A fixed order that depends on (parts, qpg) only.  A lane folding all parts itself (gn_fold_rec) waits one LDS latency per
+// record: 10 k cycles per tile at 32 parts, against a few hundred here.
+__device__ __forceinline__ void pn_fold_row(const float2* scr, int parts, int q0, int qpg, int lr, float nq, float& mean, float& var) {
+#pragma clang fp contract(off)
+  auto row_sum = [](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+  };
+  const float piv = scr[q0].x;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int p = lr; p < parts; p += 16)
+    for (int q = q0; q < q0 + qpg; ++q) {
+      const float2 v = scr[p * 16 + q];
+      const float d = v.x - piv;
+      s1 += d; s3 = __builtin_fmaf(d, d, s3); s2 += v.y;
+    }
+  s1 = row_sum(s1); s2 = row_sum(s2); s3 = row_sum(s3);
+  const float R = (float)(parts * qpg), iR = 1.0f / R;
+  mean = __builtin_fmaf(s1, iR, piv);
+  const float m2 = __builtin_fmaf(nq, fmaxf(__builtin_fmaf(-s1 * s1, iR, s3), 0.f), s2);
+  var = fmaxf(m2 / (R * nq), 0.f);
+}
 
 // acc[i][j]: cout fragment i, pixel fragment j of the wave (128 pixels x 64 couts); brv: bias (+ row vector) of the lane's run 0 in LDS
 template <typename T, typename RowFn>
@@ -156,6 +186,30 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
   const int lrp = threadIdx.x & 15;
   const int qpub = 2 * lq + 8 * (lrp & 1);                   // first quad (among the wave's 16) of the pair this lane publishes
   float* const grec = a.qstats + (((size_t)c.sample * c.parts + c.part) * (a.Cout >> 2) + ((tile_n * 128 + wn * 64) >> 2) + qpub) * 2;
+  // the raw output (when something reads it): stored while the arrival counter's round trip is in flight
+  auto store_raw = [&]() {
+    if (a.out) {
+      if (a.out_dtype == DC_F32) {
+  #pragma unroll
+        for (int j = 0; j < TM; ++j)
+  #pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            float* op = reinterpret_cast<float*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k;
+            *reinterpret_cast<f32x4*>(op) = acc[2 * k][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2 * k + 1][j];
+          }
+      } else {
+  #pragma unroll
+        for (int j = 0; j < TM; ++j)
+  #pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            float v[8];
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[2 * k + (e >> 2)][j][e & 3];
+            *reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k) = f_to_chunk<T>(v);
+          }
+      }
+    }
+  };
   bool ok = true;
   if (c.tiles == 1) {
     // ---- the whole sample is this workgroup's tile (16x16 images): the two parts meet in LDS, nothing crosses a workgroup.  The records
@@ -164,6 +218,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
     __syncthreads();                                         // every wave has left the tap loop: the scratch (a halo buffer) is free
     if (lrp < 2) *reinterpret_cast<f32x4*>(c.scr + c.part * 16 + qpub) = rec;
     __syncthreads();
+    store_raw();
   } else {
     // ---- 1./2. publish, arrive, wait for the rest of the sample.  The hand-off is the counter form measured in MI355X_MICROARCH.md
     // (inter-workgroup visibility, third row of the table of `sc1` hand-offs): every record line is written whole by ONE `sc1`
@@ -176,9 +231,10 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                         // every wave's records are out; every wave has left the tap loop (LDS is free)
     DC_STAMP(4);
+    unsigned ticket = 0;
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    store_raw();               // 64 KiB of stores per workgroup behind the add: vmcnt returns in order, so the ticket does not wait for them
     if (threadIdx.x < 64) {
-      unsigned ticket = 0;
-      if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ticket = __builtin_amdgcn_readfirstlane(ticket);
       const unsigned target = (ticket & ~(unsigned)(c.tiles - 1)) + (unsigned)c.tiles;        // tiles is a power of two
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -227,6 +283,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
   float ga[NK][8], gb[NK][8];
   {
     const float nq = 512.0f;                                 // values per record: 128 pixels x 4 channels
+    const int lr = threadIdx.x & 15;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       const int ql = 2 * lq + 8 * k;                         // the run's first quad among the wave's 16
@@ -234,12 +291,14 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
       if (c.qpg == 1) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const GnAcc A = gn_fold_rec(c.scr, c.parts, 16, ql + h, 1, nq);
-          mean[h] = A.mean; rstd[h] = rsqrtf(A.var() + c.eps);
+          float var;
+          pn_fold_row(c.scr, c.parts, ql + h, 1, lr, nq, mean[h], var);
+          rstd[h] = rsqrtf(var + c.eps);
         }
       } else {
-        const GnAcc A = gn_fold_rec(c.scr, c.parts, 16, ql / c.qpg, c.qpg, nq);
-        mean[0] = mean[1] = A.mean; rstd[0] = rstd[1] = rsqrtf(A.var() + c.eps);
+        float var;
+        pn_fold_row(c.scr, c.parts, (ql / c.qpg) * c.qpg, c.qpg, lr, nq, mean[0], var);
+        mean[1] = mean[0]; rstd[0] = rstd[1] = rsqrtf(var + c.eps);
       }
       if (!ok) rstd[0] = rstd[1] = __builtin_nanf("");     // a timed-out wait: poison what is stored, so the failure also shows downstream
       float gm[8], bt[8];
@@ -253,28 +312,7 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
     }
   }
   DC_STAMP(6);
-  // ---- 4. stores: raw (if it has a reader), then the normalised tensor ----
-  if (a.out) {
-    if (a.out_dtype == DC_F32) {
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          float* op = reinterpret_cast<float*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k;
-          *reinterpret_cast<f32x4*>(op) = acc[2 * k][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2 * k + 1][j];
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = acc[2 * k + (e >> 2)][j][e & 3];
-          *reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k) = f_to_chunk<T>(v);
-        }
-    }
-  }
+  // ---- 4. the normalised tensor (the raw one, if it has a reader, went out while the workgroup waited) ----
   // (the activation switch sits OUTSIDE the unrolled loops: a taken scalar branch per element costs ~20 cycles on this core)
   auto store_norm = [&](auto actc) {
     constexpr bool ACT = decltype(actc)::value;

@@ -916,7 +916,7 @@ def test_conv3x3_normalises_its_own_output_for_the_next_groupnorm(dt, case):
         assert torch.equal(o, o_ref)
     assert torch.isfinite(y.float()).all()
     # against the GroupNorm kernel: same records, same fold; the 16-bit kernel normalises the ROUNDED tensor, the producer its fp32 values
-    tol_k = {L.DC_F32: 2e-6, L.DC_BF16: 1.6e-2, L.DC_F16: 2e-3}[dt]
+    tol_k = {L.DC_F32: 5e-6, L.DC_BF16: 1.6e-2, L.DC_F16: 2e-3}[dt]
     assert maxrel(y, y_ref) < tol_k, maxrel(y, y_ref)
     # against torch, from the same rounded operands
     idx = smap.long().cpu() if maps else torch.arange(n)

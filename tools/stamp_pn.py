@@ -33,7 +33,8 @@ cnt = torch.zeros(n * ((Co + 127) // 128), dtype=torch.int32, device="cuda")
 plain = L.IgemmParams(out=o.data_ptr(), qstats=qs.data_ptr(), **base)
 pn = L.IgemmParams(out=o.data_ptr() if os.environ.get("RAW", "1") == "1" else None, qstats=qs.data_ptr(), pn_out=y.data_ptr(), pn_gamma=gamma.data_ptr(),
                    pn_beta=beta.data_ptr(), pn_cnt=cnt.data_ptr(), pn_ld=Co, pn_groups=32, pn_silu=1, pn_eps=1e-5, **base)
-nblk = (n * H * W // 256) * ((Co + 127) // 128)
+T_ = H * W // 256
+nblk = ((n * ((Co + 127) // 128) + 7) // 8 * 8) * T_          # the producer-normalising launch pads its grid to 8 whole groups
 st = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
 lib.dc_debug_set_stamps.argtypes = [ctypes.c_void_p]
 lib.dc_debug_set_halo_abl.argtypes = [ctypes.c_int]
@@ -53,6 +54,8 @@ for name, p, names in (("plain", plain, ["setup", "mainloop", "epi:bias", "epi:l
         e1.record()
         torch.cuda.synchronize()
         s = st.view(nblk, 8).cpu().double()
+        s = s[s[:, 7] > 0]
+        st.zero_()
         cols = [0, 1, 2, 3, 4, 5, 7] if name == "plain" else [0, 1, 2, 3, 4, 5, 6, 7]
         s = s[:, cols]
         d = s[:, 1:] - s[:, :-1]
