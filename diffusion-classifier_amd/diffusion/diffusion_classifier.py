@@ -7,7 +7,8 @@ Kept surface (same names, argument meaning, assertions and return types):
   .encode_text_prompt / .diffuse / .logsnr_schedule_cosine(_shifted)  :83-161
 `config` is the reference's attribute bag (missing keys read as None).  Additive keys read
 here: `compute_dtype` ("bf16" default | "f16" | "f32"), `units_per_launch`, `score_plan_cache` (launch plans kept, LRU;
-default 6), `shard_grid` (opt-in: True
+default 6), `dwt_on_device` (True: `inference` applies `wavelet_dec_2(images) / 2` on the device to the batches its loader yields, on the
+prefetch stream), `shard_grid` (opt-in: True
 shards the (trial, image) grid of ONE replicated batch over the default process group),
 `simulate_rank` ((r, N), bench.py only: time rank r's share of an N-rank sharded call on one GPU).
 
@@ -214,6 +215,51 @@ class DiffusionClassifier(nn.Module):
                 break
         return val_samples, batches, metrics
 
+    def prefetch_to_device(self, loader, dev):
+        """The batches of `loader` on `dev`, one batch AHEAD of the consumer: while batch i is being scored on the
+        current stream, batch i+1 is copied host -> HBM on a side stream (pinned staging, non_blocking) and — with the additive config
+        key `dwt_on_device=True`, for loaders that yield the RAW [-1, 1] images — transformed there by the HIP Haar kernel,
+        `images := wavelet_dec_2(images) / 2`, what reference dataset/chexpert.py:146-147 does per item on the host before
+        `evaluate` (:555-563) sees the batch.  The consumer's stream waits on the batch's event, so results are those of the
+        unpipelined loop.  `self._prefetch_log` keeps (copy start, copy end, handed over) events per batch for the tests."""
+        from ..utils.wavelet import wavelet_dec_2
+        side = torch.cuda.Stream(device=dev)
+        dwt = self.config.dwt_on_device is True
+        self._prefetch_log = []
+
+        def stage(batch):
+            out = {}
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(side):
+                e0.record(side)
+                for k, v in batch.items():
+                    if not torch.is_tensor(v):
+                        out[k] = v
+                        continue
+                    d = v if v.is_cuda else (v if v.is_pinned() else v.pin_memory()).to(dev, non_blocking=True)
+                    if dwt and k == "images":
+                        d = wavelet_dec_2(d, scale=0.5)          # enqueued on the side stream (L.stream_ptr() = the current stream)
+                    out[k] = d
+                e1.record(side)
+            return out, e0, e1
+
+        it = iter(loader)
+        first = next(it, None)
+        nxt = stage(first) if first is not None else None
+        while nxt is not None:
+            cur, e0, e1 = nxt
+            following = next(it, None)
+            nxt = stage(following) if following is not None else None     # batch i+1 starts moving before batch i is handed over
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(e1)
+            for v in cur.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
+            eh = torch.cuda.Event(enable_timing=True)
+            eh.record(main)
+            self._prefetch_log.append((e0, e1, eh))
+            yield cur
+
     # ---- generation (reference :163-293; SURVEY §8f row 4) ---------------------------------------------------
     # HIP backbones: ONE batch-2 plan launch per step (class token || null token, the class-independent layers once per
     # image) and ONE fused sampler-step kernel (`dc_ddpm_step`); a foreign nn.Module takes the reference's two eager calls
@@ -309,9 +355,8 @@ class DiffusionClassifier(nn.Module):
                 metric.set_device(dev)
         self.model.eval()
 
-        def on_device(loader):
-            for batch in loader:
-                yield {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        on_device = (lambda loader: self.prefetch_to_device(loader, dev)) if dev.type == "cuda" else \
+            (lambda loader: ({k: v for k, v in b.items()} for b in loader))
         val_samples, batches, metrics = self.evaluate(on_device(val_dataloader), metrics=metrics,
                                                       stop_idx=self.config.evaluation_batches,
                                                       classification=classification, from_t=from_t)

@@ -112,15 +112,19 @@ def test_cfg2_classify_bf16_bench_plan_three_anchors():
     got_l, got_e = dc.to(DEV).classify(x.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
     assert torch.isfinite(got_e).all()
     pr = pred_rel_l2(hip_preds(dc, T, BS), lp_p)
+    # Bounds: per-cell eps-MSE at <= 4x what is measured, predictions at <= 2x — the per-cell error is dominated by
+    # ||eps||^2 and barely moves when the prediction is slightly wrong, so only tight bounds make it a gate.  Measured (round 4, producer-side
+    # GroupNorm on): predictions 8.9e-3; eps-MSE 2.2e-4 / 2.9e-4 / 1.7e-4 against the three anchors (autocast itself: 2.0e-4 from fp32).
+    print(f"cfg2 bf16 predictions rel-L2 (worst sample) vs storage-rounded oracle: {pr:.2e} (bound 1.5e-2)")
     assert pr < 1.5e-2, pr                  # predictions of the benched bf16 plan vs the storage-rounded oracle, per sample
     rel = lambda a, b: ((a.float() - b.float()).abs() / b.float()).max().item()
     r_lowp, r_ac, r_f32 = rel(got_e, lp_e), rel(got_e, ac_e), rel(got_e, f32_e)
     print(f"cfg2 bf16 per-cell eps-MSE max rel err: vs storage-rounded oracle {r_lowp:.2e}, vs autocast oracle {r_ac:.2e}, "
-          f"vs fp32 oracle {r_f32:.2e}; autocast-vs-fp32 itself {rel(ac_e, f32_e):.2e}")
-    assert r_lowp < 1.5e-2, r_lowp         # same rounding points, different fp32 summation order
-    assert r_ac < 2.5e-2, r_ac             # independent bf16 rounding points on both sides
-    assert r_f32 < 2.0e-2, r_f32           # bf16 path as an approximation of the fp32 network
-    assert r_f32 < 2.5 * rel(ac_e, f32_e) + 5e-3     # ...no worse than autocast's own distance from fp32
+          f"vs fp32 oracle {r_f32:.2e}; autocast-vs-fp32 itself {rel(ac_e, f32_e):.2e}  (bounds 1e-3 / 1.2e-3 / 1e-3)")
+    assert r_lowp < 1.0e-3, r_lowp         # same rounding points, different fp32 summation order
+    assert r_ac < 1.2e-3, r_ac             # independent bf16 rounding points on both sides
+    assert r_f32 < 1.0e-3, r_f32           # bf16 path as an approximation of the fp32 network
+    assert r_f32 < 2.5 * rel(ac_e, f32_e) + 2e-4     # ...no worse than autocast's own distance from fp32
     means = f32_e.mean(2)
     srt = means.sort(1).values
     decided = (srt[:, 1] - srt[:, 0]) / srt[:, 0] > 2 * r_f32
@@ -178,8 +182,8 @@ def test_cfg4_ipmsa_unet_forward_bf16():
     assert torch.isfinite(got).all()
     r, r32 = relerr(got, ref), relerr(got, ref32)
     print(f"cfg4 bf16 forward rel-L2: vs storage-rounded oracle {r:.2e}, vs fp32 oracle {r32:.2e}")
-    assert r < 2e-2, r
-    assert r32 < 4e-2, r32
+    assert r < 1.6e-2, r           # <= 2x the measured 8.2e-3 / 9.1e-3
+    assert r32 < 1.8e-2, r32
     plan = next(iter(m._plans.values()))
     names = [mt["name"] for mt in plan.pb.meta]
     assert "down_blocks.4.resnets.3.conv1" in names                    # down_blocks.4 has four ResNets (tuple layers_per_block)
@@ -283,7 +287,7 @@ def test_cfg5_dit_b4_full_depth_f16_forward_and_classify():
     got = md(x.to(DEV), lam.to(DEV), lab.to(DEV)).cpu()
     r = relerr(got, ref)
     print(f"cfg5 DiT-B/4 12-layer f16 forward rel-L2 vs fp16-storage oracle: {r:.2e}")
-    assert r < 6e-3, r
+    assert r < 1.4e-3, r           # <= 2x the measured 7.2e-4
     cfg = dict(CFG2, encoder_type="DiT", classes=2, evaluation_per_stage=[2], image_size=128, noise_d=128, compute_dtype="f16")
     dc = dca.DiffusionClassifier(m.cpu(), dca.Config(**cfg)).to(DEV)
     oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
@@ -296,8 +300,49 @@ def test_cfg5_dit_b4_full_depth_f16_forward_and_classify():
     rel = ((got_e - ref_e).abs() / ref_e).max().item()
     pr = pred_rel_l2(hip_preds(dc, T, BS), ref_p)
     print(f"cfg5 DiT-B/4 f16 classify per-cell eps-MSE max rel err: {rel:.2e}; predictions rel-L2 (worst sample) {pr:.2e}")
-    assert rel < 5e-3, rel
-    assert pr < 6e-3, pr
+    assert rel < 1e-5, rel         # <= 4x the measured 2.4e-6
+    assert pr < 1.4e-3, pr         # <= 2x the measured 7.1e-4
+    gap = abs(ref_e.mean(2)[0, 0] - ref_e.mean(2)[0, 1]) / ref_e.mean(2).min()
+    if gap > 2 * rel:
+        assert got_l.cpu().tolist() == ref_l.tolist()
+
+
+def test_cfg5_raw_dit_b4_4096_tokens_f16_forward_and_classify():
+    """BASELINE config 5' — models/chexpert-256-dit-b4.py:7-13 with wavelet_transform=False: the raw 3x256x256 image, patch 4 ->
+    4096 tokens per sample (the flash attention's long-sequence case at model level; cfg 5 proper is the 1024-token DWT form).  Two
+    transformer layers deep (the CPU oracle's attention is 4096^2 per head), f16: one forward, then a 2-class x 1-trial classify,
+    against the oracle with fp16 storage rounding."""
+    kw = dict(dca.chexpert_dit_b4_kwargs(False), num_embeds_ada_norm=4, num_layers=2)
+    assert (kw["sample_size"], kw["in_channels"], kw["patch_size"]) == (256, 3, 4)
+    torch.manual_seed(91)
+    m = dca.DiT(**kw)
+    _randomise_vectors(m)
+    o = oracle.OracleDiT(**kw, lowp=True, lowp_dtype=torch.float16)
+    o.load_state_dict(m.state_dict())
+    torch.manual_seed(92)
+    x, lam, lab = torch.randn(1, 3, 256, 256) * 0.5, torch.tensor([1.5]), torch.tensor([1])
+    with torch.no_grad():
+        ref = o(x, lam, lab)
+    md = m.to(DEV).set_compute_dtype("f16")
+    got = md(x.to(DEV), lam.to(DEV), lab.to(DEV)).cpu()
+    r = relerr(got, ref)
+    print(f"cfg5' raw DiT-B/4 (2 layers, 4096 tokens) f16 forward rel-L2 vs fp16-storage oracle: {r:.2e}")
+    assert r < 1.5e-3, r
+    cfg = dict(CFG2, encoder_type="DiT", classes=2, evaluation_per_stage=[1], image_size=256, noise_d=256, compute_dtype="f16")
+    dc = dca.DiffusionClassifier(m.cpu(), dca.Config(**cfg)).to(DEV)
+    oc = oracle.OracleDiffusionClassifier(o, oracle.AttrBag(**cfg))
+    torch.manual_seed(93)
+    xx = torch.rand(1, 3, 256, 256) * 2 - 1
+    t, eps = torch.rand(1, 1), torch.randn(1, 1, 3, 256, 256)
+    ref_l, ref_e, ref_p = oc.classify(xx, t=t, eps=eps, return_errors=True, return_preds=True)
+    got_l, got_e = dc.classify(xx.to(DEV), t=t, eps=eps.to(DEV), return_errors=True)
+    rel = ((got_e - ref_e).abs() / ref_e).max().item()
+    pr = pred_rel_l2(hip_preds(dc, 1, 1), ref_p)
+    print(f"cfg5' raw DiT-B/4 f16 classify per-cell eps-MSE max rel err: {rel:.2e}; predictions rel-L2 (worst sample) {pr:.2e}")
+    assert rel < 2e-5, rel
+    assert pr < 1.5e-3, pr
+    plan = next(iter(dc._score_plans.values()))["plan"]
+    assert any(mt.get("family") == "attention" and mt.get("flops", 0) > 0 for mt in plan.pb.meta)
     gap = abs(ref_e.mean(2)[0, 0] - ref_e.mean(2)[0, 1]) / ref_e.mean(2).min()
     if gap > 2 * rel:
         assert got_l.cpu().tolist() == ref_l.tolist()
@@ -329,8 +374,8 @@ def test_cfg3_inputs_are_the_haar_transform_of_the_image():
     rel = ((got_e - ref_e).abs() / ref_e).max().item()
     pr = pred_rel_l2(hip_preds(dc, 1, 1), ref_p)
     print(f"cfg3 bf16 classify (1 trial x 2 classes) per-cell eps-MSE max rel err: {rel:.2e}; predictions rel-L2 (worst sample) {pr:.2e}")
-    assert rel < 2e-2, rel
-    assert pr < 2e-2, pr
+    assert rel < 4e-5, rel         # <= 4x the measured 1.0e-5 (3.4e-6 before the producer normalised its fp32 accumulators instead of the rounded tensor)
+    assert pr < 1.2e-2, pr         # <= 2x the measured 5.9e-3
 
 
 def test_cfg2_full_grid_properties_at_bench_size():

@@ -22,6 +22,8 @@ def family(kernel):
     if "conv3_halo_kernel" in k or "conv3_halo_pers_kernel" in k:     # <T, NW, (GN,) NTAP, ...>: the persistent form is the same family
         if len(ints) > 1 and ints[1] == 4:                      # NTAP = 4: the four-phase upsample conv
             return f"conv3_up4<{dt},{ints[0]}w>"
+        if re.search(r"Lb[01]ELb1EE", k) or re.search(r"(true|false),true>", k):   # <..., STG, PN = true>: producer-side GroupNorm
+            return f"conv3_halo<{dt},{ints[0]}w,pn>"
         return f"conv3_halo<{dt},{ints[0]}w>"
     if "conv3_ws_kernel" in k or "conv3_wsp_kernel" in k:      # <T, GN>: wave-specialised halo conv (the persistent form is the same family)
         gn = "Lb1E" in k or "true" in k
