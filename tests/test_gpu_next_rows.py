@@ -82,6 +82,7 @@ def test_inference_prefetches_the_next_batch_and_transforms_it_on_the_side_strea
     loader = [{"images": (torch.rand(16, 3, 64, 64, generator=g) * 2 - 1), "prompt": torch.randint(0, 4, (16,), generator=g)} for _ in range(4)]
 
     def run(pipelined):
+        torch.manual_seed(5)                                   # (the constructor draws the class-embedding table)
         dc = dca.DiffusionClassifier(model, dca.Config(**dict(cfg, dwt_on_device=pipelined))).to(DEV)
         torch.manual_seed(11)
         torch.cuda.manual_seed(11)
