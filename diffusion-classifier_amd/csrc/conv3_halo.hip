@@ -73,7 +73,7 @@ DC_CLOCK_DECL(conv3_halo)
 // (epi_pn.h).  The workgroups of one (sample, N tile) then sit on consecutive block indices (see there).
 template <typename T, int NW, int NTAP = 9, int MODE = 0, bool STG = false, bool PN = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
-  static_assert(!PN || (MODE == 1 && NW == 4 && NTAP == 9 && !STG), "producer-side GroupNorm: the one-image-per-patch 3x3 form");
+  static_assert(!PN || (MODE == 1 && NW == 4 && !STG), "producer-side GroupNorm: the one-image-per-patch forms (3x3, four-phase upsample)");
   static_assert(!STG || NW == 8, "staggered loop: the 8-wave kernel");
   constexpr bool XB = MODE == 1, MOS = MODE == 2;
   using Cfg = HaloCfg<NW>;
@@ -98,12 +98,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     // grid is padded to a multiple of 8 groups; the surplus workgroups leave at once.  (With the groups on consecutive BLOCK indices
     // instead, their members sat in different queues, the queues drifted apart, and a 16-tile group waited 30 k cycles of a 60 k-cycle
     // tile for its slowest member — stamps, tools/stamp_pn.py; correctness never depends on the placement, see epi_pn.h.)
+    // Four-phase upsample conv (NTAP = 4): the output sample is written by the four phases of every low-resolution tile, so a group is
+    // 4 x 2^lpt workgroups — position (phase, tile) inside it — and a.tiles_n counts phase-major N tiles (4 x the real ones).
+    constexpr int LPH = NTAP == 4 ? 2 : 0;
+    const int tnr = a.tiles_n >> LPH;                         // real N tiles
     const int kq = blockIdx.x >> 3;
-    const int grp = ((kq >> g.lpt) << 3) + (blockIdx.x & 7);
-    if (grp >= g.n_img * a.tiles_n) return;
-    const int smp = grp / a.tiles_n;
-    tile_n = __builtin_amdgcn_readfirstlane(grp - smp * a.tiles_n);
-    tile_m = __builtin_amdgcn_readfirstlane((smp << g.lpt) + (kq & ((1 << g.lpt) - 1)));
+    const int grp = ((kq >> (g.lpt + LPH)) << 3) + (blockIdx.x & 7);
+    if (grp >= g.n_img * tnr) return;
+    const int smp = grp / tnr;
+    const int within = kq & ((1 << (g.lpt + LPH)) - 1);
+    tile_n = __builtin_amdgcn_readfirstlane((within >> g.lpt) * tnr + grp - smp * tnr);
+    tile_m = __builtin_amdgcn_readfirstlane((smp << g.lpt) + (within & ((1 << g.lpt) - 1)));
     asm volatile("" : "+s"(tile_m), "+s"(tile_n));
   } else if constexpr (XB) tile_of_block_scalar(a, tile_m, tile_n);     // buffer-descriptor loaders: scalar offsets must be SGPRs (no waterfall loops)
   else tile_of_block(a, tile_m, tile_n);
@@ -614,13 +619,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   };
   if constexpr (PN) {
     PnCtx pc;
-    pc.sample = ng; pc.part = ((ty * g.tiles_x + tx) << 1) + wm; pc.parts = HW >> 7; pc.tiles = 1 << g.lpt;
+    // (four-phase upsample: every phase contributes its own parts of the output sample, and all four wait for each other)
+    pc.sample = ng; pc.part = (UP4 ? phase * (HW >> 7) : 0) + ((ty * g.tiles_x + tx) << 1) + wm;
+    pc.parts = (HW >> 7) << (UP4 ? 2 : 0); pc.tiles = 1 << (g.lpt + (UP4 ? 2 : 0));
     pc.qpg = (a.Cout / a.pn_groups) >> 2;
-    pc.cnt = a.pn_cnt + (size_t)ng * a.tiles_n + tile_n; pc.timeouts = &g_pn_timeouts;
+    pc.cnt = a.pn_cnt + (size_t)ng * (UP4 ? a.tiles_n >> 2 : a.tiles_n) + tile_n; pc.timeouts = &g_pn_timeouts;
     pc.gam = brv + 128 + wn * 64 + lq * 8; pc.bet = brv + 256 + wn * 64 + lq * 8;
     // records of the wave's 64 channels: a sample of several tiles -> per wave (<= 32 parts x 128 B); one tile -> the two parts meet in an
     // area shared by the two waves of the N half
-    pc.scr = reinterpret_cast<float2*>(g.lpt ? smem + wave * 4096 : smem + wn * 256);
+    pc.scr = reinterpret_cast<float2*>(pc.tiles > 1 ? smem + wave * 4096 : smem + wn * 256);
     pc.flag = reinterpret_cast<int*>(brv + 384);
     pc.eps = a.pn_eps; pc.silu = a.pn_silu;
     epi_halo_pn<T>(a, acc, tile_n, wn, lq, rowfn, brv + wn * 64 + lq * 8, pc);
@@ -892,10 +899,10 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   if (a.pn_out) {
     // producer-side GroupNorm (epi_pn.h): one-image-per-patch form only; dc_conv3_halo_pn_ok said so, this is the launch-time proof
     if constexpr (NW == 4) {
-      if (!g.xbuf || up4 || ni != 1) { dc_set_error("conv3_halo: producer-side GroupNorm needs the one-image-per-patch 3x3 form"); return DC_ERR_SHAPE; }
-      static bool pn_attr = false;
-      kern = conv3_halo_kernel<T, 4, 9, 1, false, true>;
-      if (!pn_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS); pn_attr = true; }
+      if (!g.xbuf || ni != 1) { dc_set_error("conv3_halo: producer-side GroupNorm needs the one-image-per-patch form"); return DC_ERR_SHAPE; }
+      static bool pn_attr[2] = {false, false};
+      kern = up4 ? conv3_halo_kernel<T, 4, 4, 1, false, true> : conv3_halo_kernel<T, 4, 9, 1, false, true>;
+      if (!pn_attr[up4 ? 1 : 0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS); pn_attr[up4 ? 1 : 0] = true; }
     } else {
       dc_set_error("conv3_halo: producer-side GroupNorm needs images of at least 16x16"); return DC_ERR_SHAPE;
     }
@@ -920,8 +927,8 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   }
   long long grid = nblk;
   if (a.pn_out) {          // whole groups of 2^lpt workgroups, a multiple of 8 of them (PN block order, see the kernel)
-    const long long groups = (long long)n_img * a.tiles_n;
-    grid = ((groups + 7) / 8 * 8) << g.lpt;
+    const long long groups = (long long)n_img * (up4 ? a.tiles_n >> 2 : a.tiles_n);
+    grid = ((groups + 7) / 8 * 8) << (g.lpt + (up4 ? 2 : 0));
     if (grid > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", grid); return DC_ERR_SHAPE; }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS, s, a, g);
@@ -932,11 +939,13 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
 // most 16 workgroups and 32 quad-record parts per sample), Cout a multiple of 128 whose GroupNorm groups are 4 ... 32 channels wide
 // (a group never leaves a wave's 64 channels); output (raw and normalised) in the compute type
 constexpr int PN_MAX_TILES = 16;
-bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype) {
+bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype, bool up4) {
   static const bool off = getenv("DCAMD_NO_PN") != nullptr;
-  if (off || !dc_conv3_halo_applicable(a, dtype) || a.upsample || a.src1) return false;
-  const int H = a.Hin, W = a.Win;
-  if (H < 16 || W < 16 || H * W < 256 || (H * W) / 256 > PN_MAX_TILES) return false;
+  if (off || a.src1) return false;
+  // four-phase upsample conv: the kernel walks the low-resolution image, and the four phases of every tile share the output sample
+  if (up4 ? !(a.upsample && dc_conv3_up4_applicable(a, dtype)) : (a.upsample || !dc_conv3_halo_applicable(a, dtype))) return false;
+  const int H = up4 ? a.Hin >> 1 : a.Hin, W = up4 ? a.Win >> 1 : a.Win;
+  if (H < 16 || W < 16 || H * W < 256 || ((H * W) / 256) * (up4 ? 4 : 1) > PN_MAX_TILES) return false;
   if (a.Cout % 128 || a.pn_groups <= 0 || a.Cout % a.pn_groups) return false;
   const int cpg = a.Cout / a.pn_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16 && cpg != 32) return false;

@@ -314,11 +314,6 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   const char* dn = p->dtype == DC_BF16 ? "bf16" : (p->dtype == DC_F16 ? "f16" : "f32");
   const bool halo_ok = bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype);
   // four-phase upsample conv (W in the phase-summed form): the caller opted in, so anything else is an error
-  if (p->up4 && p->pn_out) {      // the four-phase upsample conv does not normalise its own output (its sample spans four phases' workgroups)
-    if (variant) { *variant = "producer-groupnorm-unsupported"; return DC_ERR_UNSUPPORTED; }
-    dc_set_error("dc_igemm: pn_out given with up4 (see dc_igemm_pn_ok)");
-    return DC_ERR_UNSUPPORTED;
-  }
   if (p->up4) {
     const bool up4_halo = bn == 128 && !use_v1 && !no_halo && !a.src1 && dc_conv3_up4_applicable(a, p->dtype) &&
                           (!a.qstats || (p->out_dtype == p->dtype && p->Cout % 8 == 0 && ((uintptr_t)a.qstats & 15) == 0 &&
@@ -327,6 +322,16 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     const bool up4_pipe = !up4_halo && bn == 128 && !use_v1 && !a.src1 && !a.qstats && p->taps == 9 && p->stride == 1 &&
                           p->upsample && p->act == DC_ACT_NONE && !p->gate && !p->residual && !a.gn_scale && !a.src2 &&
                           p->Hin >= 4 && p->Win >= 4 && p->Hin % 2 == 0 && p->Win % 2 == 0 && (p->Hin < 16 || p->Win < 16);
+    if (p->pn_out) {      // producer-side GroupNorm on the four-phase form: the 4-wave one-image-per-patch kernel only (sources of 16x16 and more)
+      const bool pn_ok = up4_halo && a.Hin > 16 && a.Win > 16 && dc_conv3_halo_pn_ok(a, p->dtype, true) && a.qstats && a.pn_gamma && a.pn_beta && a.pn_cnt &&
+                         p->out_dtype == p->dtype && a.pn_ld % 8 == 0 && a.pn_ld >= p->Cout && (((uintptr_t)a.pn_out | (uintptr_t)a.qstats) & 15) == 0 &&
+                         ((uintptr_t)a.pn_cnt & 3) == 0 && a.pn_eps > 0.f;
+      if (!pn_ok) {
+        if (variant) { *variant = "producer-groupnorm-unsupported"; return DC_ERR_UNSUPPORTED; }
+        dc_set_error("dc_igemm: pn_out given but this upsample conv cannot normalise its own output (see dc_igemm_pn_ok)");
+        return DC_ERR_UNSUPPORTED;
+      }
+    }
     if (!up4_halo && !up4_pipe) {
       if (variant) { *variant = "up4-unsupported"; return DC_ERR_UNSUPPORTED; }
       dc_set_error("dc_igemm: up4 given but this problem cannot take the four-phase upsample conv (see dc_igemm_up4_ok)");
@@ -334,7 +339,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     }
     if (variant) {
       static thread_local char name4[64];
-      if (up4_halo) snprintf(name4, sizeof(name4), "conv3_up4<%s,%dw>", dn, (a.Hin <= 16 || a.Win <= 16) ? 8 : 4);
+      if (up4_halo) snprintf(name4, sizeof(name4), p->pn_out ? "conv3_up4<%s,%dw,pn>" : "conv3_up4<%s,%dw>", dn, (a.Hin <= 16 || a.Win <= 16) ? 8 : 4);
       else snprintf(name4, sizeof(name4), "igemm_pipe_up4<%s,256x128,3st>", dn);
       *variant = name4;
       return DC_OK;
@@ -376,7 +381,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   // producer-side GroupNorm: the caller opted in (dc_igemm_pn_ok), anything that cannot take it is an error
   const bool use_pn = a.pn_out != nullptr;
   if (use_pn) {
-    const bool pn_ok = halo_ok && !use_ws && !a.gn_scale && !dc_conv3_thin_applicable(a, p->dtype) && dc_conv3_halo_pn_ok(a, p->dtype) &&
+    const bool pn_ok = halo_ok && !use_ws && !a.gn_scale && !dc_conv3_thin_applicable(a, p->dtype) && dc_conv3_halo_pn_ok(a, p->dtype, false) &&
                        a.qstats && a.pn_gamma && a.pn_beta && a.pn_cnt && p->out_dtype == p->dtype && a.pn_ld % 8 == 0 && a.pn_ld >= p->Cout &&
                        (((uintptr_t)a.pn_out | (uintptr_t)a.qstats) & 15) == 0 && ((uintptr_t)a.pn_cnt & 3) == 0 && a.pn_eps > 0.f;
     if (!pn_ok) {

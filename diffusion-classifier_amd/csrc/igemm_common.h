@@ -165,7 +165,7 @@ int dc_conv3_halo_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s
 bool dc_conv3_up4_applicable(const IgemmArgs& a, int dtype);   // upsample + 3x3 conv as four 2x2-tap phases
 int dc_conv3_up4_launch(const IgemmArgs& a, int dtype, int n_img, hipStream_t s);
 int dc_igemm_launch_pipe_up4(const IgemmArgs& a, int dtype, hipStream_t s);   // the same on the tap-gather kernel (sources < 8x8)
-bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype);      // producer-side GroupNorm possible (epi_pn.h)
+bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype, bool up4);   // producer-side GroupNorm possible (epi_pn.h)
 unsigned dc_conv3_halo_pn_timeouts();                          // reads and clears the device-side failure counter (synchronous)
 // conv3_ws.hip: wave-specialised halo conv (loader / transform waves + MFMA waves) with the input's GroupNorm(+SiLU) fused in
 bool dc_conv3_ws_ok(const IgemmArgs& a, int dtype);

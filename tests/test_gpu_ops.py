@@ -1097,6 +1097,60 @@ def test_upsample_conv_as_four_phases(dt, shape):
     assert ((m2_got - m2_ref).abs() / m2_ref).max().item() < (1e-4 if dt == L.DC_F32 else 1e-2)
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("shape", [(9, 16, 16, 128, 128, 16), (3, 32, 32, 64, 256, 32), (40, 16, 16, 128, 128, 32)])
+def test_upsample_conv_normalises_its_own_output(dt, shape):
+    """Producer-side GroupNorm on the four-phase upsample conv (dc_igemm up4 + pn_*): the output sample is written by the four phases
+    of every low-resolution tile, which exchange their quad records like the tiles of a plain conv do.  Raw output and records equal
+    the plain up4 launch bit for bit; the normalised output equals dc_groupnorm on those records / torch within the dtype's rounding."""
+    torch.manual_seed(88)
+    n, H, W, Ci, Co, groups = shape
+    lib = L.lib()
+    q = lambda t: t.to(TD[dt]).float()
+    x0 = q(torch.randn(n, Ci, H, W))
+    w = q(torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5))
+    b = torch.randn(Co).to(DEV)
+    a0, W4 = nhwc(x0, dt), E.pack_up4(w, dt, DEV)
+    Ho, Wo = 2 * H, 2 * W
+    kw = dict(dtype=dt, taps=9, stride=1, upsample=1, n_img=n, Hin=Ho, Win=Wo, Hout=Ho, Wout=Wo, src0=ptr(a0), C0=Ci, W=ptr(W4), Cout=Co, tile_n=128,
+              bias=ptr(b), out_dtype=dt, out_ld=Co, up4=1)
+    o_ref = torch.full((n, Ho, Wo, Co), float("nan"), device=DEV).to(TD[dt])
+    parts = lib.dc_igemm_qstats_parts(L.IgemmParams(out=ptr(o_ref), **kw))
+    assert parts == Ho * Wo // 128
+    q_ref = torch.full((n, parts, Co // 4, 2), float("nan"), device=DEV)
+    run_igemm(out=ptr(o_ref), qstats=ptr(q_ref), **kw)
+    gamma, beta = (torch.randn(Co) * 0.5 + 1).to(DEV), torch.randn(Co).to(DEV)
+    splits = lib.dc_groupnorm_splits(n, Ho * Wo, Co)
+    wsb = torch.zeros(lib.dc_groupnorm_ws_floats(n, groups, splits), device=DEV)
+    y_ref = torch.empty_like(o_ref)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(x=ptr(o_ref), y=ptr(y_ref), dtype=dt, out_dtype=dt, n=n, HW=Ho * Wo, C=Co, C1=0, groups=groups, silu=1,
+                                               splits=splits, eps=1e-5, gamma=ptr(gamma), beta=ptr(beta), ws=ptr(wsb), qstats=ptr(q_ref), qparts=parts),
+                             L.stream_ptr()), "gn")
+    o = torch.full((n, Ho, Wo, Co), float("nan"), device=DEV).to(TD[dt])
+    y = torch.full((n, Ho, Wo, Co), float("nan"), device=DEV).to(TD[dt])
+    q_o = torch.full((n, parts, Co // 4, 2), float("nan"), device=DEV)
+    cnt = torch.zeros(n * ((Co + 127) // 128), dtype=torch.int32, device=DEV)
+    pp = L.IgemmParams(out=ptr(o), qstats=ptr(q_o), pn_out=ptr(y), pn_gamma=ptr(gamma), pn_beta=ptr(beta), pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=groups,
+                       pn_silu=1, pn_eps=1e-5, **kw)
+    assert lib.dc_igemm_pn_ok(pp) == 1
+    assert lib.dc_igemm_variant(pp).decode() == "conv3_up4<%s,4w,pn>" % {L.DC_F32: "f32", L.DC_BF16: "bf16", L.DC_F16: "f16"}[dt]
+    for _ in range(2):
+        L.check(lib.dc_igemm(pp, L.stream_ptr()), "upsample conv with producer-side GroupNorm")
+    torch.cuda.synchronize()
+    assert lib.dc_pn_timeouts() == 0
+    assert torch.equal(cnt, torch.full_like(cnt, 2 * 4 * (H * W // 256)))
+    assert torch.equal(q_o, q_ref) and torch.equal(o, o_ref)
+    assert torch.isfinite(y.float()).all()
+    assert maxrel(y, y_ref) < {L.DC_F32: 5e-6, L.DC_BF16: 1.6e-2, L.DC_F16: 2e-3}[dt], maxrel(y, y_ref)
+    ref = F.conv2d(F.interpolate(x0, scale_factor=2.0, mode="nearest"), w, b.cpu(), padding=1)
+    yn = F.silu(F.group_norm(ref, groups, gamma.cpu(), beta.cpu(), 1e-5))
+    assert maxrel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 3e-5, L.DC_BF16: 1.2e-2, L.DC_F16: 2e-3}[dt]
+    # a source below 16x16 runs on the 8-wave patch, which does not exchange statistics: refused
+    small = L.IgemmParams(**dict(kw, n_img=n, Hin=16, Win=16, Hout=16, Wout=16), out=ptr(o), qstats=ptr(q_o), pn_out=ptr(y), pn_gamma=ptr(gamma),
+                          pn_beta=ptr(beta), pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=groups, pn_silu=1, pn_eps=1e-5)
+    assert lib.dc_igemm_pn_ok(small) == 0
+
+
 @pytest.mark.parametrize("shape", [(5, 10, 50, 50, 3), (3, 6, 7, 3, 2), (2, 100, 9, 9, 1), (4, 1000, 4, 2, 7)])
 def test_stage_topk_and_argmin_match_torch(shape):
     """dc_stage_topk / dc_reduce_argmin: mean over the evaluated trials + k smallest classes per image (reference
