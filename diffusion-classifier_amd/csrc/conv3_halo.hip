@@ -73,7 +73,10 @@ DC_CLOCK_DECL(conv3_halo)
 // (epi_pn.h).  The workgroups of one (sample, N tile) then sit on consecutive block indices (see there).
 template <typename T, int NW, int NTAP = 9, int MODE = 0, bool STG = false, bool PN = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
-  static_assert(!PN || (MODE == 1 && NW == 4 && !STG), "producer-side GroupNorm: the one-image-per-patch forms (3x3, four-phase upsample)");
+  // PN with NW = 4: images that span workgroups (statistics exchanged through memory, epi_pn.h).  PN with NW = 8 (8x8 images, staggered loop):
+  // every image lies inside one wave, the statistics never leave it (igemm_epilogue.h, EpiPnLocal8x8).
+  static_assert(!PN || (MODE == 1 && NW == 4 && !STG) || (MODE == 0 && NW == 8 && STG && NTAP == 9), "producer-side GroupNorm: one-image-per-patch forms, or 8x8 images");
+  constexpr bool PNX = PN && NW == 4, PNL = PN && NW == 8;
   static_assert(!STG || NW == 8, "staggered loop: the 8-wave kernel");
   constexpr bool XB = MODE == 1, MOS = MODE == 2;
   using Cfg = HaloCfg<NW>;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
   const int wm = wave >> 1, wn = wave & 1;      // NW/2 waves along pixels, 2 along couts
   const int lr = lane & 15, lq = lane >> 4;
   int tile_m, tile_n;
-  if constexpr (PN) {
+  if constexpr (PNX) {
     // The workgroups that share a sample's statistics — a group: (sample, N tile) x the 2^lpt tiles of the image — sit on CONSECUTIVE
     // positions of ONE XCD's dispatch queue: blocks are dealt round-robin to the 8 XCDs (b and b + 8 share one), so position k = b >> 3
     // of queue b & 7 is tile k & (2^lpt - 1) of that queue's group k >> lpt, and the groups are dealt round-robin to the queues.  The
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     }
     brv[t] = v;
   }
-  if constexpr (PN) {      // gamma / beta of the consumer's GroupNorm for this N tile, behind the bias table
+  if constexpr (PNX) {     // gamma / beta of the consumer's GroupNorm for this N tile, behind the bias table
     if (t >= 128 && t < 256) {
       const int c = tile_n * 128 + t - 128;
       brv[t] = a.pn_gamma[c];
@@ -617,7 +620,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     r.o = UP4 ? n * (4 * HW) + (2 * (ty * th + py) + pa) * (2 * g.W) + 2 * (tx * tw + px) + pb : n * HW + rem;
     r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
   };
-  if constexpr (PN) {
+  if constexpr (PNL) {
+    epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, rowfn, EpiNoPre(), qsfn, EpiNoBias(), EpiPnLocal8x8());
+  } else if constexpr (PNX) {
     PnCtx pc;
     // (four-phase upsample: every phase contributes its own parts of the output sample, and all four wait for each other)
     pc.sample = ng; pc.part = (UP4 ? phase * (HW >> 7) : 0) + ((ty * g.tiles_x + tx) << 1) + wm;
@@ -896,15 +901,18 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", nblk); return DC_ERR_SHAPE; }
   if (g.xbuf) kern = up4 ? conv3_halo_kernel<T, NW, 4, 1> : conv3_halo_kernel<T, NW, 9, 1>;
+  bool pn_local = false;
   if (a.pn_out) {
-    // producer-side GroupNorm (epi_pn.h): one-image-per-patch form only; dc_conv3_halo_pn_ok said so, this is the launch-time proof
+    // producer-side GroupNorm: images that span workgroups -> the one-image-per-patch form with the exchange of epi_pn.h; 8x8 images ->
+    // the staggered 8-wave kernel, every image inside one wave; dc_conv3_halo_pn_ok said so, this is the launch-time proof
     if constexpr (NW == 4) {
       if (!g.xbuf || ni != 1) { dc_set_error("conv3_halo: producer-side GroupNorm needs the one-image-per-patch form"); return DC_ERR_SHAPE; }
       static bool pn_attr[2] = {false, false};
       kern = up4 ? conv3_halo_kernel<T, 4, 4, 1, false, true> : conv3_halo_kernel<T, 4, 9, 1, false, true>;
       if (!pn_attr[up4 ? 1 : 0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS); pn_attr[up4 ? 1 : 0] = true; }
     } else {
-      dc_set_error("conv3_halo: producer-side GroupNorm needs images of at least 16x16"); return DC_ERR_SHAPE;
+      if (up4 || g.mos || g.xbuf || g.H != 8 || g.W != 8 || ni != 8) { dc_set_error("conv3_halo: producer-side GroupNorm on the 8-wave patch needs 8x8 images"); return DC_ERR_SHAPE; }
+      pn_local = true;
     }
   }
   if constexpr (NW == 8) {
@@ -912,9 +920,10 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
     // staggered wave groups (STG) unless DCAMD_HALO_NO_STAG (read per call: A/B runs in one process)
     // (the four-tap upsample form stays on the lock-step loop: its whole next halo would ride in one MFMA block — measured slower)
     if (!up4 && !getenv("DCAMD_HALO_NO_STAG") && (long long)a.tiles_n * 128 * a.Ktot * (long long)sizeof(T) < (1LL << 31)) {
-      const int mode = g.mos ? 2 : (g.xbuf ? 1 : 0);
-      static bool stg_attr[3] = {false, false, false};
+      const int mode = pn_local ? 3 : (g.mos ? 2 : (g.xbuf ? 1 : 0));
+      static bool stg_attr[4] = {false, false, false, false};
       switch (mode) {
+        case 3: kern = conv3_halo_kernel<T, NW, 9, 0, true, true>; break;
         case 0: kern = conv3_halo_kernel<T, NW, 9, 0, true>; break;
         case 1: kern = conv3_halo_kernel<T, NW, 9, 1, true>; break;
         default: kern = conv3_halo_kernel<T, NW, 9, 2, true>; break;
@@ -925,8 +934,11 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
       }
     }
   }
+  if constexpr (NW == 8) {
+    if (pn_local && kern != conv3_halo_kernel<T, 8, 9, 0, true, true>) { dc_set_error("conv3_halo: producer-side GroupNorm on 8x8 images needs the staggered loop"); return DC_ERR_SHAPE; }
+  }
   long long grid = nblk;
-  if (a.pn_out) {          // whole groups of 2^lpt workgroups, a multiple of 8 of them (PN block order, see the kernel)
+  if (a.pn_out && !pn_local) {          // whole groups of 2^lpt workgroups, a multiple of 8 of them (PN block order, see the kernel)
     const long long groups = (long long)n_img * (up4 ? a.tiles_n >> 2 : a.tiles_n);
     grid = ((groups + 7) / 8 * 8) << (g.lpt + (up4 ? 2 : 0));
     if (grid > 0x7fffffffLL) { dc_set_error("conv3_halo: bad grid %lld", grid); return DC_ERR_SHAPE; }
@@ -942,6 +954,13 @@ constexpr int PN_MAX_TILES = 16;
 bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype, bool up4) {
   static const bool off = getenv("DCAMD_NO_PN") != nullptr;
   if (off || a.src1) return false;
+  if (!up4 && a.Hin == 8 && a.Win == 8) {      // 8x8 images: the staggered 8-wave kernel, statistics inside one wave (EpiPnLocal8x8)
+    if (a.upsample || !dc_conv3_halo_applicable(a, dtype) || getenv("DCAMD_HALO_NO_STAG")) return false;
+    if (a.Cout % 128 || a.pn_groups <= 0 || a.Cout % a.pn_groups) return false;
+    const int cpg8 = a.Cout / a.pn_groups;
+    if (cpg8 != 4 && cpg8 != 8 && cpg8 != 16 && cpg8 != 32) return false;
+    return (long long)a.tiles_n * 128 * a.Ktot * dc_dtype_size(dtype) < (1LL << 31);
+  }
   // four-phase upsample conv: the kernel walks the low-resolution image, and the four phases of every tile share the output sample
   if (up4 ? !(a.upsample && dc_conv3_up4_applicable(a, dtype)) : (a.upsample || !dc_conv3_halo_applicable(a, dtype))) return false;
   const int H = up4 ? a.Hin >> 1 : a.Hin, W = up4 ? a.Win >> 1 : a.Win;

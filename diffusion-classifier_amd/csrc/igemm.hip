@@ -406,7 +406,7 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
     static thread_local char name[64];
     if (thin) { snprintf(name, sizeof(name), "conv3_thin<%s>", dn); *variant = name; return DC_OK; }
     if (use_ws) snprintf(name, sizeof(name), a.gn_scale ? "conv3_ws<%s,gn>" : "conv3_ws<%s>", dn);
-    else if (use_pn) snprintf(name, sizeof(name), "conv3_halo<%s,4w,pn>", dn);
+    else if (use_pn) snprintf(name, sizeof(name), "conv3_halo<%s,%dw,pn>", dn, (a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && !no_halo && dc_conv3_halo_applicable(a, p->dtype)) snprintf(name, sizeof(name), "conv3_halo<%s,%dw>", dn, (a.Hin <= 8 || a.Win <= 8) ? 8 : 4);
     else if (bn == 128 && !use_v1 && use_xreg) snprintf(name, sizeof(name), "igemm_xreg<%s,96xN>", dn);
     else if (bn == 128 && !use_v1) {

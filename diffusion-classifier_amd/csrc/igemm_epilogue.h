@@ -66,6 +66,11 @@ struct EpiNoBias {
 // the output sample and part index of pixel fragments [4 half, 4 half + 4) of the wave (wave-uniform), false when that
 // sample does not exist; qsfn.whole(): both halves belong to the same (sample, part) and are written as one record.
 template <int V> struct EpiIC { static constexpr int value = V; };
+// wave-local producer-side GroupNorm (conv3_halo's 8x8-image form: every image of the patch lies inside one wave's 128 pixels, two per
+// wave): PnL::on selects the code — the epilogue then ALSO stores act(GroupNorm(v)) of its output v into IgemmArgs::pn_out, from the
+// quad records it forms anyway; nothing crosses a wave (csrc/epi_pn.h is the form for images that span several workgroups)
+struct EpiNoPnLocal { static constexpr bool on = false; };
+struct EpiPnLocal8x8 { static constexpr bool on = true; };
 struct EpiNoQs {
   static constexpr bool on = false;
   __device__ __forceinline__ bool operator()(int, int&, int&) const { return false; }
@@ -74,10 +79,11 @@ struct EpiNoQs {
 };
 
 template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn, typename PreFn = EpiNoPre, typename QsFn = EpiNoQs,
-          typename BiasFn = EpiNoBias>
+          typename BiasFn = EpiNoBias, typename PnL = EpiNoPnLocal>
 __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[4][TM], int tile_n, int wn, int lq,
                                                int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn(), QsFn qsfn = QsFn(),
-                                               BiasFn biasfn = BiasFn()) {
+                                               BiasFn biasfn = BiasFn(), PnL = PnL()) {
+  static_assert(!PnL::on || (QsFn::on && TM == 8 && ACT == DC_ACT_NONE && !GATE), "wave-local GroupNorm: the plain 128-pixel halo epilogue with quad statistics");
   constexpr bool geglu = ACT == DC_ACT_GEGLU;
   constexpr int NK = geglu ? 1 : 2;                  // 8-channel runs per pixel
   constexpr int JB = TM;                             // pixel fragments per load batch: all of them — one exposed residual latency per tile
@@ -240,6 +246,12 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
   // inside S' and Q' is the spread BETWEEN the channels of a quad, which is part of the group's variance anyway.
   // Fixed order: the result depends on the tile geometry only.  The fp32 values are taken BEFORE the rounding to T (the
   // re-conversion cost as much as the sums): they differ from the stored tensor's statistics by ~2^-9 / sqrt(count) relative.
+  float pnr[PnL::on ? 2 : 1][NK][4];                    // wave-local GroupNorm: the quad records of the wave's two images (every lane of a row holds them)
+  float pgm[PnL::on ? NK : 1][8], pbt[PnL::on ? NK : 1][8];
+  if constexpr (PnL::on) {                              // gamma / beta of the lane's runs, fetched in front of every store of the wave
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { ld8(a.pn_gamma + c0 + 32 * k, pgm[k]); ld8(a.pn_beta + c0 + 32 * k, pbt[k]); }
+  }
   if constexpr (QsFn::on) {
     static_assert(!QsFn::on || (TM == 8 && ACT != DC_ACT_GEGLU), "quad statistics: 128-pixel wave tiles, plain epilogue");
     if (a.qstats) {
@@ -293,6 +305,12 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
             r[k][2 * qd] = __builtin_fmaf(S, inv_n, piv[k][qd]);
             r[k][2 * qd + 1] = fmaxf(__builtin_fmaf(-S * S, inv_n, Q), 0.f);
           }
+        if constexpr (PnL::on) {
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pnr[h][k][e] = r[k][e];
+        }
         int n = 0, part = 0;
         if ((threadIdx.x & 15) == 0 && qsfn(h, n, part)) {
 #pragma unroll
@@ -309,27 +327,113 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     }
   }
   // ---- phase B: conversions and stores only (one straight-line sequence per output type) ----
-  if (a.out_dtype == DC_F32) {
+  auto store_all = [&](void* outp, int ld, int odt) {
+    if (odt == DC_F32) {
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+      for (int j = 0; j < TM; ++j)
 #pragma unroll
-      for (int k = 0; k < NK; ++k)
-        if (orow[j] >= 0 && con[k]) {
-          float* op = reinterpret_cast<float*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k;
-          if (geglu) { *reinterpret_cast<f32x4*>(op) = acc[0][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2][j]; }
-          else { *reinterpret_cast<f32x4*>(op) = acc[2 * k][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2 * k + 1][j]; }
-        }
+        for (int k = 0; k < NK; ++k)
+          if (orow[j] >= 0 && con[k]) {
+            float* op = reinterpret_cast<float*>(outp) + (size_t)orow[j] * ld + c0 + 32 * k;
+            if (geglu) { *reinterpret_cast<f32x4*>(op) = acc[0][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2][j]; }
+            else { *reinterpret_cast<f32x4*>(op) = acc[2 * k][j]; *reinterpret_cast<f32x4*>(op + 4) = acc[2 * k + 1][j]; }
+          }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+          if (orow[j] >= 0 && con[k]) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = geglu ? acc[(e >> 2) * 2][j][e & 3] : acc[2 * k + (e >> 2)][j][e & 3];
+            *reinterpret_cast<chunk16*>(reinterpret_cast<T*>(outp) + (size_t)orow[j] * ld + c0 + 32 * k) = f_to_chunk<T>(v);
+          }
+    }
+  };
+  if constexpr (!PnL::on) {
+    store_all(a.out, a.out_ld, a.out_dtype);
   } else {
+    // ---- wave-local producer-side GroupNorm (8x8 images: pixel fragments 0-3 are one image, 4-7 the next): raw store (if the raw tensor
+    // has a reader), then the group statistics from the quad records of each image — merged over the group's quads in channel order,
+    // with the lanes 16 / 32 apart that hold the group's other quads when a group is wider than a run — and y = act(v a + b) in place
+    if (a.out) store_all(a.out, a.out_ld, a.out_dtype);
+    const int qpg = (a.Cout / a.pn_groups) >> 2;             // quads per group: 1, 2, 4 or 8
+    const float nq = 256.0f;                                 // values per quad record: 64 pixels x 4 channels
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int k = 0; k < NK; ++k)
-        if (orow[j] >= 0 && con[k]) {
-          float v[8];
+      for (int k = 0; k < NK; ++k) {
+        // the (mean, M2) sets of the group(s) of this run's two quads
+        float gm[2], gv[2];
+        if (qpg == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = geglu ? acc[(e >> 2) * 2][j][e & 3] : acc[2 * k + (e >> 2)][j][e & 3];
-          *reinterpret_cast<chunk16*>(reinterpret_cast<T*>(a.out) + (size_t)orow[j] * a.out_ld + c0 + 32 * k) = f_to_chunk<T>(v);
+          for (int qd = 0; qd < 2; ++qd) { gm[qd] = pnr[h][k][2 * qd]; gv[qd] = pnr[h][k][2 * qd + 1] / nq; }
+        } else {
+#pragma clang fp contract(off)
+          // sets in channel order; a lane pair / quadruple orders them alike, so every lane of the group ends with the same bits
+          float ms[8], m2[8];
+          ms[0] = pnr[h][k][0]; m2[0] = pnr[h][k][1]; ms[1] = pnr[h][k][2]; m2[1] = pnr[h][k][3];
+          int nset = 2;
+          if (qpg >= 4) {
+            const bool hi = lq & 1;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(pnr[h][k][e], 16);
+            const float a0 = ms[0], a1 = m2[0], a2 = ms[1], a3 = m2[1];
+            ms[0] = hi ? o[0] : a0; m2[0] = hi ? o[1] : a1; ms[1] = hi ? o[2] : a2; m2[1] = hi ? o[3] : a3;
+            ms[2] = hi ? a0 : o[0]; m2[2] = hi ? a1 : o[1]; ms[3] = hi ? a2 : o[2]; m2[3] = hi ? a3 : o[3];
+            nset = 4;
+            if (qpg == 8) {
+              const bool hi2 = lq & 2;
+              float p[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { p[2 * e] = __shfl_xor(ms[e], 32); p[2 * e + 1] = __shfl_xor(m2[e], 32); }
+              float cm[4], c2[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { cm[e] = ms[e]; c2[e] = m2[e]; }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                ms[e] = hi2 ? p[2 * e] : cm[e]; m2[e] = hi2 ? p[2 * e + 1] : c2[e];
+                ms[4 + e] = hi2 ? cm[e] : p[2 * e]; m2[4 + e] = hi2 ? c2[e] : p[2 * e + 1];
+              }
+              nset = 8;
+            }
+          }
+          float sm = 0.f, s2 = 0.f;
+          for (int i = 0; i < nset; ++i) { sm += ms[i]; s2 += m2[i]; }
+          const float mean = sm / (float)nset;
+          float sd = 0.f;
+          for (int i = 0; i < nset; ++i) { const float d = ms[i] - mean; sd = __builtin_fmaf(d, d, sd); }
+          gm[0] = gm[1] = mean;
+          gv[0] = gv[1] = fmaxf(__builtin_fmaf(nq, sd, s2) / (nq * (float)nset), 0.f);
         }
+        float ga[8], gb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sc = rsqrtf(gv[e >> 2] + a.pn_eps) * pgm[k][e];
+          ga[e] = sc; gb[e] = pbt[k][e] - gm[e >> 2] * sc;
+        }
+        if (a.pn_silu) {
+#pragma unroll
+          for (int jj = 0; jj < TM / 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3];
+              acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3] = silu_t<T>(x * ga[e] + gb[e]);
+            }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < TM / 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3];
+              acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3] = x * ga[e] + gb[e];
+            }
+        }
+      }
+    }
+    store_all(a.pn_out, a.pn_ld, sizeof(T) == 4 ? DC_F32 : (int)a.out_dtype);
   }
 }
 

@@ -975,6 +975,81 @@ def test_producer_normalised_conv_never_reads_a_previous_launch_s_records(n):
     assert bad == 0, bad
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("case", ["c256_cpg8_res_maps_raw", "c512_cpg16_nosilu_raw", "c128_cpg4", "c1024_cpg32", "c256_ragged_patch_side"])
+def test_conv3x3_on_8x8_images_normalises_its_own_output_inside_the_wave(dt, case):
+    """Producer-side GroupNorm on 8x8 images (the staggered 8-wave halo kernel: two whole images per wave): the group statistics come
+    from the quad records the epilogue forms anyway and never leave the wave (groups wider than a lane's 8-channel run are merged
+    with the lanes 16 / 32 apart).  Raw output and records equal the plain launch's bit for bit; the normalised output equals
+    dc_groupnorm on those records / torch; sample counts that leave a patch (8 images) ragged."""
+    torch.manual_seed(91)
+    n, Ci, Co, groups, res, maps, silu, raw, side = {
+        "c256_cpg8_res_maps_raw": (21, 128, 256, 32, True, True, True, True, 0),
+        "c512_cpg16_nosilu_raw": (9, 128, 512, 32, False, False, False, True, 0),
+        "c128_cpg4": (16, 128, 128, 32, False, False, True, False, 0),
+        "c1024_cpg32": (5, 64, 1024, 32, False, False, True, False, 0),
+        "c256_ragged_patch_side": (11, 128, 256, 16, True, False, True, True, 128)}[case]
+    H = W = 8
+    q = lambda t: t.to(TD[dt]).float()
+    lib = L.lib()
+    eps = 1e-5 if silu else 1e-6
+    n_src = 4 if maps else n
+    smap = torch.tensor([i % n_src for i in range(n)], dtype=torch.int32, device=DEV) if maps else None
+    x = q(torch.randn(n_src, Ci, H, W))
+    w = q(torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5))
+    b, rv = torch.randn(Co).to(DEV), (torch.randn(n, Co) * 2).to(DEV)
+    a0, Wp = nhwc(x, dt), E.pack_conv3x3(w, dt, DEV)
+    r = torch.randn(n_src if maps else n, H, W, Co, device=DEV).to(TD[dt]) if res else None
+    xs = q(torch.randn(n_src if maps else n, side, H, W)) if side else None
+    ws2 = q(torch.randn(Co, side) / side ** 0.5) if side else None
+    ck = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=Ci, map0=ptr(smap), W=ptr(Wp), Cout=Co,
+              tile_n=128, bias=ptr(b), rowvec=ptr(rv), rowvec_ld=Co, out_dtype=dt, out_ld=Co)
+    keep = []
+    if res:
+        ck.update(residual=ptr(r), res_map=ptr(smap), res_dtype=dt, res_ld=Co)
+    if side:
+        a2, W2 = nhwc(xs, dt), E.pack_matrix(ws2, dt, DEV)
+        keep += [a2, W2]
+        ck.update(src2=ptr(a2), map2=ptr(smap), W2=ptr(W2), C2=side, ld2=side)
+    o_ref = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    parts = lib.dc_igemm_qstats_parts(L.IgemmParams(out=ptr(o_ref), **ck))
+    assert parts == 1
+    q_ref = torch.full((n, parts, Co // 4, 2), float("nan"), device=DEV)
+    run_igemm(out=ptr(o_ref), qstats=ptr(q_ref), **ck)
+    gamma, beta = (torch.randn(Co) * 0.5 + 1).to(DEV), torch.randn(Co).to(DEV)
+    splits = lib.dc_groupnorm_splits(n, H * W, Co)
+    wsb = torch.zeros(lib.dc_groupnorm_ws_floats(n, groups, splits), device=DEV)
+    y_ref = torch.empty_like(o_ref)
+    L.check(lib.dc_groupnorm(L.GroupnormParams(x=ptr(o_ref), y=ptr(y_ref), dtype=dt, out_dtype=dt, n=n, HW=H * W, C=Co, C1=0, groups=groups, silu=int(silu),
+                                               splits=splits, eps=eps, gamma=ptr(gamma), beta=ptr(beta), ws=ptr(wsb), qstats=ptr(q_ref), qparts=parts),
+                             L.stream_ptr()), "gn")
+    o = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt]) if raw else None
+    y = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    q_o = torch.full((n, parts, Co // 4, 2), float("nan"), device=DEV)
+    cnt = torch.zeros(n * ((Co + 127) // 128), dtype=torch.int32, device=DEV)
+    pp = L.IgemmParams(out=ptr(o), qstats=ptr(q_o), pn_out=ptr(y), pn_gamma=ptr(gamma), pn_beta=ptr(beta), pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=groups,
+                       pn_silu=int(silu), pn_eps=eps, **ck)
+    assert lib.dc_igemm_pn_ok(pp) == 1
+    assert lib.dc_igemm_variant(pp).decode() == "conv3_halo<%s,8w,pn>" % {L.DC_F32: "f32", L.DC_BF16: "bf16", L.DC_F16: "f16"}[dt]
+    L.check(lib.dc_igemm(pp, L.stream_ptr()), "8x8 conv with wave-local GroupNorm")
+    torch.cuda.synchronize()
+    assert torch.equal(q_o, q_ref)
+    if raw:
+        assert torch.equal(o, o_ref)
+    assert torch.isfinite(y.float()).all()
+    assert maxrel(y, y_ref) < {L.DC_F32: 5e-6, L.DC_BF16: 1.6e-2, L.DC_F16: 2e-3}[dt], maxrel(y, y_ref)
+    idx = smap.long().cpu() if maps else torch.arange(n)
+    ref = F.conv2d(x[idx], w, b.cpu(), padding=1) + rv.cpu()[:, :, None, None]
+    if side:
+        ref = ref + torch.einsum("nchw,oc->nohw", xs[idx], ws2)
+    if res:
+        ref = ref + r.float().cpu()[idx].permute(0, 3, 1, 2)
+    yn = F.group_norm(ref, groups, gamma.cpu(), beta.cpu(), eps)
+    if silu:
+        yn = F.silu(yn)
+    assert maxrel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 3e-5, L.DC_BF16: 1.0e-2, L.DC_F16: 1.5e-3}[dt]
+
+
 def test_groupnorm_span_kernel_opt_in():
     """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
     test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
