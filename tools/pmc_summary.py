@@ -3,7 +3,10 @@
 profiles/pmc_traffic.json: per kernel FAMILY (the names bench.py / dc_igemm_variant use) the per-launch
 averages of FETCH_SIZE and WRITE_SIZE in KB.  bench.py applies the gfx950 correction (FETCH_SIZE x2) itself.
 
-  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json "comment"
+  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json "comment" [workload]
+
+With a fifth argument the record is MERGED into the existing file under "workloads" / <workload> (bench.py reads the other BASELINE
+configurations' traffic from there); without it the file is rewritten with the headline workload's families at the top level.
 """
 import csv
 import glob
@@ -68,12 +71,24 @@ def collect(root, counter):
 
 def main():
     fetch_dir, write_dir, out, comment = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    workload = sys.argv[5] if len(sys.argv) > 5 else None
     ft, fc = collect(fetch_dir, "FETCH_SIZE")
     wt, wc = collect(write_dir, "WRITE_SIZE")
     rec = {"_comment": comment}
     for fam in sorted(ft):
         rec[fam] = {"fetch_kb_per_launch": round(ft[fam] / fc[fam], 1),
                     "write_kb_per_launch": round(wt.get(fam, 0.0) / max(wc.get(fam, 0), 1), 1), "launches": fc[fam]}
+    if workload:
+        import os
+        full = json.load(open(out)) if os.path.exists(out) else {}
+        full.setdefault("workloads", {})[workload] = rec
+        rec = full
+    else:
+        import os
+        if os.path.exists(out):            # keep the other workloads' records
+            old = json.load(open(out)).get("workloads")
+            if old:
+                rec["workloads"] = old
     json.dump(rec, open(out, "w"), indent=1)
     for k, v in rec.items():
         print(k, v)
