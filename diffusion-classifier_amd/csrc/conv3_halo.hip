@@ -75,7 +75,7 @@ template <typename T, int NW, int NTAP = 9, int MODE = 0, bool STG = false, bool
 __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs a, const HaloGeom g) {
   // PN with NW = 4: images that span workgroups (statistics exchanged through memory, epi_pn.h).  PN with NW = 8 (8x8 images, staggered loop):
   // every image lies inside one wave, the statistics never leave it (igemm_epilogue.h, EpiPnLocal8x8).
-  static_assert(!PN || (MODE == 1 && NW == 4 && !STG) || (MODE == 0 && NW == 8 && STG && NTAP == 9), "producer-side GroupNorm: one-image-per-patch forms, or 8x8 images");
+  static_assert(!PN || (MODE == 1 && NW == 4 && !STG) || ((MODE == 0 || MODE == 2) && NW == 8 && STG && NTAP == 9), "producer-side GroupNorm: one-image-per-patch forms, or 8x8 / 4x4 images");
   constexpr bool PNX = PN && NW == 4, PNL = PN && NW == 8;
   static_assert(!STG || NW == 8, "staggered loop: the 8-wave kernel");
   constexpr bool XB = MODE == 1, MOS = MODE == 2;
@@ -620,7 +620,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3_halo_kernel(const IgemmArgs 
     r.o = UP4 ? n * (4 * HW) + (2 * (ty * th + py) + pa) * (2 * g.W) + 2 * (tx * tw + px) + pb : n * HW + rem;
     r.r = (a.residual && a.res_map ? a.res_map[n] : n) * HW + rem;
   };
-  if constexpr (PNL) {
+  if constexpr (PNL && MOS) {
+    epi_direct_act<T, TM, DC_ACT_NONE, false, false>(a, acc, tile_n, wn, lq, nw0, nw1, rowfn, EpiNoPre(), qsfn, EpiNoBias(), EpiPnLocal4x4());
+  } else if constexpr (PNL) {
     epi_direct_act<T, TM, DC_ACT_NONE, false, true>(a, acc, tile_n, wn, lq, nw0, nw1, rowfn, EpiNoPre(), qsfn, EpiNoBias(), EpiPnLocal8x8());
   } else if constexpr (PNX) {
     PnCtx pc;
@@ -911,7 +913,8 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
       kern = up4 ? conv3_halo_kernel<T, 4, 4, 1, false, true> : conv3_halo_kernel<T, 4, 9, 1, false, true>;
       if (!pn_attr[up4 ? 1 : 0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS); pn_attr[up4 ? 1 : 0] = true; }
     } else {
-      if (up4 || g.mos || g.xbuf || g.H != 8 || g.W != 8 || ni != 8) { dc_set_error("conv3_halo: producer-side GroupNorm on the 8-wave patch needs 8x8 images"); return DC_ERR_SHAPE; }
+      const bool i8 = !g.mos && !g.xbuf && g.H == 8 && g.W == 8 && ni == 8, i4 = g.mos && g.H == 4 && g.W == 4 && ni == 32;
+      if (up4 || !(i8 || i4)) { dc_set_error("conv3_halo: producer-side GroupNorm on the 8-wave patch needs 8x8 or 4x4 images"); return DC_ERR_SHAPE; }
       pn_local = true;
     }
   }
@@ -920,9 +923,10 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
     // staggered wave groups (STG) unless DCAMD_HALO_NO_STAG (read per call: A/B runs in one process)
     // (the four-tap upsample form stays on the lock-step loop: its whole next halo would ride in one MFMA block — measured slower)
     if (!up4 && !getenv("DCAMD_HALO_NO_STAG") && (long long)a.tiles_n * 128 * a.Ktot * (long long)sizeof(T) < (1LL << 31)) {
-      const int mode = pn_local ? 3 : (g.mos ? 2 : (g.xbuf ? 1 : 0));
-      static bool stg_attr[4] = {false, false, false, false};
+      const int mode = pn_local ? (g.mos ? 4 : 3) : (g.mos ? 2 : (g.xbuf ? 1 : 0));
+      static bool stg_attr[5] = {false, false, false, false, false};
       switch (mode) {
+        case 4: kern = conv3_halo_kernel<T, NW, 9, 2, true, true>; break;
         case 3: kern = conv3_halo_kernel<T, NW, 9, 0, true, true>; break;
         case 0: kern = conv3_halo_kernel<T, NW, 9, 0, true>; break;
         case 1: kern = conv3_halo_kernel<T, NW, 9, 1, true>; break;
@@ -935,7 +939,7 @@ static int launch_halo(const IgemmArgs& a0, int n_img, hipStream_t s, bool up4 =
     }
   }
   if constexpr (NW == 8) {
-    if (pn_local && kern != conv3_halo_kernel<T, 8, 9, 0, true, true>) { dc_set_error("conv3_halo: producer-side GroupNorm on 8x8 images needs the staggered loop"); return DC_ERR_SHAPE; }
+    if (pn_local && kern != conv3_halo_kernel<T, 8, 9, 0, true, true> && kern != conv3_halo_kernel<T, 8, 9, 2, true, true>) { dc_set_error("conv3_halo: producer-side GroupNorm on 8x8 images needs the staggered loop"); return DC_ERR_SHAPE; }
   }
   long long grid = nblk;
   if (a.pn_out && !pn_local) {          // whole groups of 2^lpt workgroups, a multiple of 8 of them (PN block order, see the kernel)
@@ -954,7 +958,8 @@ constexpr int PN_MAX_TILES = 16;
 bool dc_conv3_halo_pn_ok(const IgemmArgs& a, int dtype, bool up4) {
   static const bool off = getenv("DCAMD_NO_PN") != nullptr;
   if (off || a.src1) return false;
-  if (!up4 && a.Hin == 8 && a.Win == 8) {      // 8x8 images: the staggered 8-wave kernel, statistics inside one wave (EpiPnLocal8x8)
+  if (!up4 && ((a.Hin == 8 && a.Win == 8) || (a.Hin == 4 && a.Win == 4 && !getenv("DCAMD_NO_MOSAIC")))) {
+    // 8x8 / 4x4 images: the staggered 8-wave kernel, every image inside one wave, the statistics never leave it (EpiPnLocal8x8 / 4x4)
     if (a.upsample || !dc_conv3_halo_applicable(a, dtype) || getenv("DCAMD_HALO_NO_STAG")) return false;
     if (a.Cout % 128 || a.pn_groups <= 0 || a.Cout % a.pn_groups) return false;
     const int cpg8 = a.Cout / a.pn_groups;

@@ -198,7 +198,7 @@ extern "C" int32_t dc_igemm_pn_ok(const dc_igemm_params* p) {
   dc_igemm_params q = *p;
   alignas(16) static float dummy[4] = {0.f, 0.f, 0.f, 0.f};
   if (!q.pn_out) q.pn_out = dummy;
-  if (!q.qstats) q.qstats = dummy;
+  if (!q.qstats && !(q.Hin == 4 && q.Win == 4)) q.qstats = dummy;      // (4x4 mosaic patches form no quad records: their GroupNorm needs none)
   if (!q.pn_gamma) q.pn_gamma = dummy;
   if (!q.pn_beta) q.pn_beta = dummy;
   if (!q.pn_cnt) q.pn_cnt = reinterpret_cast<uint32_t*>(dummy);
@@ -382,8 +382,8 @@ static int igemm_run(const dc_igemm_params* p, dc_stream stream, const char** va
   const bool use_pn = a.pn_out != nullptr;
   if (use_pn) {
     const bool pn_ok = halo_ok && !use_ws && !a.gn_scale && !dc_conv3_thin_applicable(a, p->dtype) && dc_conv3_halo_pn_ok(a, p->dtype, false) &&
-                       a.qstats && a.pn_gamma && a.pn_beta && a.pn_cnt && p->out_dtype == p->dtype && a.pn_ld % 8 == 0 && a.pn_ld >= p->Cout &&
-                       (((uintptr_t)a.pn_out | (uintptr_t)a.qstats) & 15) == 0 && ((uintptr_t)a.pn_cnt & 3) == 0 && a.pn_eps > 0.f;
+                       (a.qstats || (a.Hin == 4 && a.Win == 4)) && a.pn_gamma && a.pn_beta && a.pn_cnt && p->out_dtype == p->dtype && a.pn_ld % 8 == 0 &&
+                       a.pn_ld >= p->Cout && (((uintptr_t)a.pn_out | (uintptr_t)a.qstats) & 15) == 0 && ((uintptr_t)a.pn_cnt & 3) == 0 && a.pn_eps > 0.f;
     if (!pn_ok) {
       if (variant) { *variant = "producer-groupnorm-unsupported"; return DC_ERR_UNSUPPORTED; }
       dc_set_error("dc_igemm: pn_out given but this problem cannot normalise its own output (see dc_igemm_pn_ok)");

@@ -69,8 +69,9 @@ template <int V> struct EpiIC { static constexpr int value = V; };
 // wave-local producer-side GroupNorm (conv3_halo's 8x8-image form: every image of the patch lies inside one wave's 128 pixels, two per
 // wave): PnL::on selects the code — the epilogue then ALSO stores act(GroupNorm(v)) of its output v into IgemmArgs::pn_out, from the
 // quad records it forms anyway; nothing crosses a wave (csrc/epi_pn.h is the form for images that span several workgroups)
-struct EpiNoPnLocal { static constexpr bool on = false; };
-struct EpiPnLocal8x8 { static constexpr bool on = true; };
+struct EpiNoPnLocal { static constexpr bool on = false; static constexpr int IMG_FR = 4; };
+struct EpiPnLocal8x8 { static constexpr bool on = true; static constexpr int IMG_FR = 4; };     // an image = 4 pixel fragments of the wave (records from `emit`)
+struct EpiPnLocal4x4 { static constexpr bool on = true; static constexpr int IMG_FR = 1; };     // mosaic patches: an image = ONE fragment (16 pixels); no quad records exist
 struct EpiNoQs {
   static constexpr bool on = false;
   __device__ __forceinline__ bool operator()(int, int&, int&) const { return false; }
@@ -83,7 +84,7 @@ template <typename T, int TM, int ACT, bool GATE, bool TWO_SAMP, typename RowFn,
 __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[4][TM], int tile_n, int wn, int lq,
                                                int samp_first, int samp_last, RowFn rowfn, PreFn prefn = PreFn(), QsFn qsfn = QsFn(),
                                                BiasFn biasfn = BiasFn(), PnL = PnL()) {
-  static_assert(!PnL::on || (QsFn::on && TM == 8 && ACT == DC_ACT_NONE && !GATE), "wave-local GroupNorm: the plain 128-pixel halo epilogue with quad statistics");
+  static_assert(!PnL::on || (TM == 8 && ACT == DC_ACT_NONE && !GATE && (QsFn::on || PnL::IMG_FR == 1)), "wave-local GroupNorm: the plain 128-pixel halo epilogue");
   constexpr bool geglu = ACT == DC_ACT_GEGLU;
   constexpr int NK = geglu ? 1 : 2;                  // 8-channel runs per pixel
   constexpr int JB = TM;                             // pixel fragments per load batch: all of them — one exposed residual latency per tile
@@ -246,7 +247,7 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
   // inside S' and Q' is the spread BETWEEN the channels of a quad, which is part of the group's variance anyway.
   // Fixed order: the result depends on the tile geometry only.  The fp32 values are taken BEFORE the rounding to T (the
   // re-conversion cost as much as the sums): they differ from the stored tensor's statistics by ~2^-9 / sqrt(count) relative.
-  float pnr[PnL::on ? 2 : 1][NK][4];                    // wave-local GroupNorm: the quad records of the wave's two images (every lane of a row holds them)
+  float pnr[(PnL::on && PnL::IMG_FR == 4) ? 2 : 1][NK][4];                    // wave-local GroupNorm: the quad records of the wave's two images (every lane of a row holds them)
   float pgm[PnL::on ? NK : 1][8], pbt[PnL::on ? NK : 1][8];
   if constexpr (PnL::on) {                              // gamma / beta of the lane's runs, fetched in front of every store of the wave
 #pragma unroll
@@ -305,7 +306,7 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
             r[k][2 * qd] = __builtin_fmaf(S, inv_n, piv[k][qd]);
             r[k][2 * qd + 1] = fmaxf(__builtin_fmaf(-S * S, inv_n, Q), 0.f);
           }
-        if constexpr (PnL::on) {
+        if constexpr (PnL::on && PnL::IMG_FR == 4) {
 #pragma unroll
           for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -358,28 +359,55 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
     // has a reader), then the group statistics from the quad records of each image — merged over the group's quads in channel order,
     // with the lanes 16 / 32 apart that hold the group's other quads when a group is wider than a run — and y = act(v a + b) in place
     if (a.out) store_all(a.out, a.out_ld, a.out_dtype);
+    constexpr int IFR = PnL::IMG_FR, NIMG = TM / IFR;       // pixel fragments per image, images per wave
     const int qpg = (a.Cout / a.pn_groups) >> 2;             // quads per group: 1, 2, 4 or 8
-    const float nq = 256.0f;                                 // values per quad record: 64 pixels x 4 channels
+    const float nq = (float)(IFR * 64);                      // values per quad record: 16 pixels x 4 channels per fragment
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NIMG; ++h) {
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
-        // the (mean, M2) sets of the group(s) of this run's two quads
+        float rq[4];                                         // (mean, M2) of the run's two quads over image h
+        if constexpr (IFR == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rq[e] = pnr[h][k][e];
+        } else {
+          // one fragment per image: the shifted sums of `emit`, over the row's 16 pixels (no quad records are written for mosaic patches)
+#pragma clang fp contract(off)
+          auto share0l = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xF, 0xF, true)); };
+          auto row_suml = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+            return v;
+          };
+#pragma unroll
+          for (int qd = 0; qd < 2; ++qd) {
+            const float pv = share0l(acc[2 * k + qd][h][0]);
+            float sm_ = 0.f, sq_ = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = acc[2 * k + qd][h][e] - pv; sm_ += d; sq_ = __builtin_fmaf(d, d, sq_); }
+            const float S = row_suml(sm_), Q = row_suml(sq_);
+            rq[2 * qd] = __builtin_fmaf(S, 1.0f / 64.0f, pv);
+            rq[2 * qd + 1] = fmaxf(__builtin_fmaf(-S * S, 1.0f / 64.0f, Q), 0.f);
+          }
+        }
+        // the (mean, variance) of the group(s) of this run's two quads
         float gm[2], gv[2];
         if (qpg == 1) {
 #pragma unroll
-          for (int qd = 0; qd < 2; ++qd) { gm[qd] = pnr[h][k][2 * qd]; gv[qd] = pnr[h][k][2 * qd + 1] / nq; }
+          for (int qd = 0; qd < 2; ++qd) { gm[qd] = rq[2 * qd]; gv[qd] = rq[2 * qd + 1] / nq; }
         } else {
 #pragma clang fp contract(off)
           // sets in channel order; a lane pair / quadruple orders them alike, so every lane of the group ends with the same bits
           float ms[8], m2[8];
-          ms[0] = pnr[h][k][0]; m2[0] = pnr[h][k][1]; ms[1] = pnr[h][k][2]; m2[1] = pnr[h][k][3];
+          ms[0] = rq[0]; m2[0] = rq[1]; ms[1] = rq[2]; m2[1] = rq[3];
           int nset = 2;
           if (qpg >= 4) {
             const bool hi = lq & 1;
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(pnr[h][k][e], 16);
+            for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(rq[e], 16);
             const float a0 = ms[0], a1 = m2[0], a2 = ms[1], a3 = m2[1];
             ms[0] = hi ? o[0] : a0; m2[0] = hi ? o[1] : a1; ms[1] = hi ? o[2] : a2; m2[1] = hi ? o[3] : a3;
             ms[2] = hi ? a0 : o[0]; m2[2] = hi ? a1 : o[1]; ms[3] = hi ? a2 : o[2]; m2[3] = hi ? a3 : o[3];
@@ -416,19 +444,19 @@ __device__ __forceinline__ void epi_direct_act(const IgemmArgs& a, f32x4 (&acc)[
         }
         if (a.pn_silu) {
 #pragma unroll
-          for (int jj = 0; jj < TM / 2; ++jj)
+          for (int jj = 0; jj < IFR; ++jj)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float x = acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3];
-              acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3] = silu_t<T>(x * ga[e] + gb[e]);
+              const float x = acc[2 * k + (e >> 2)][h * IFR + jj][e & 3];
+              acc[2 * k + (e >> 2)][h * IFR + jj][e & 3] = silu_t<T>(x * ga[e] + gb[e]);
             }
         } else {
 #pragma unroll
-          for (int jj = 0; jj < TM / 2; ++jj)
+          for (int jj = 0; jj < IFR; ++jj)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float x = acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3];
-              acc[2 * k + (e >> 2)][h * (TM / 2) + jj][e & 3] = x * ga[e] + gb[e];
+              const float x = acc[2 * k + (e >> 2)][h * IFR + jj][e & 3];
+              acc[2 * k + (e >> 2)][h * IFR + jj][e & 3] = x * ga[e] + gb[e];
             }
         }
       }

@@ -1050,6 +1050,70 @@ def test_conv3x3_on_8x8_images_normalises_its_own_output_inside_the_wave(dt, cas
     assert maxrel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 3e-5, L.DC_BF16: 1.0e-2, L.DC_F16: 1.5e-3}[dt]
 
 
+@pytest.mark.parametrize("dt", [L.DC_F32, L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("case", ["c512_cpg16_res_raw", "c256_cpg8_nosilu_side_maps", "c1024_cpg32", "c128_cpg4_ragged"])
+def test_conv3x3_on_4x4_images_normalises_its_own_output_inside_the_wave(dt, case):
+    """Producer-side GroupNorm on 4x4 images (mosaic halo patches: 32 images per workgroup, one per 16-pixel MFMA fragment): the
+    statistics of an image are the sums over ONE fragment row of the wave — formed in the epilogue, no quad records exist for these
+    patches — merged over the group's quads like the 8x8 form.  Raw output equals the plain launch's bit for bit; the normalised
+    output equals dc_groupnorm of the raw fp32 / rounded tensor and torch within the dtype's rounding."""
+    torch.manual_seed(92)
+    n, Ci, Co, groups, res, maps, silu, raw, side = {
+        "c512_cpg16_res_raw": (70, 128, 512, 32, True, False, True, True, 0),
+        "c256_cpg8_nosilu_side_maps": (45, 128, 256, 32, True, True, False, True, 128),
+        "c1024_cpg32": (33, 64, 1024, 32, False, False, True, False, 0),
+        "c128_cpg4_ragged": (37, 128, 128, 32, False, False, True, False, 0)}[case]
+    H = W = 4
+    q = lambda t: t.to(TD[dt]).float()
+    lib = L.lib()
+    eps = 1e-5 if silu else 1e-6
+    n_src = 7 if maps else n
+    smap = torch.tensor([i % n_src for i in range(n)], dtype=torch.int32, device=DEV) if maps else None
+    x = q(torch.randn(n_src, Ci, H, W))
+    w = q(torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5))
+    b, rv = torch.randn(Co).to(DEV), (torch.randn(n, Co) * 2).to(DEV)
+    a0, Wp = nhwc(x, dt), E.pack_conv3x3(w, dt, DEV)
+    r = torch.randn(n_src if maps else n, H, W, Co, device=DEV).to(TD[dt]) if res else None
+    xs = q(torch.randn(n_src if maps else n, side, H, W)) if side else None
+    ws2 = q(torch.randn(Co, side) / side ** 0.5) if side else None
+    ck = dict(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(a0), C0=Ci, map0=ptr(smap), W=ptr(Wp), Cout=Co,
+              tile_n=128, bias=ptr(b), rowvec=ptr(rv), rowvec_ld=Co, out_dtype=dt, out_ld=Co)
+    keep = []
+    if res:
+        ck.update(residual=ptr(r), res_map=ptr(smap), res_dtype=dt, res_ld=Co)
+    if side:
+        a2, W2 = nhwc(xs, dt), E.pack_matrix(ws2, dt, DEV)
+        keep += [a2, W2]
+        ck.update(src2=ptr(a2), map2=ptr(smap), W2=ptr(W2), C2=side, ld2=side)
+    o_ref = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    assert lib.dc_igemm_qstats_parts(L.IgemmParams(out=ptr(o_ref), **ck)) == 0          # mosaic patches write no quad records
+    run_igemm(out=ptr(o_ref), **ck)
+    gamma, beta = (torch.randn(Co) * 0.5 + 1).to(DEV), torch.randn(Co).to(DEV)
+    o = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt]) if raw else None
+    y = torch.full((n, H, W, Co), float("nan"), device=DEV).to(TD[dt])
+    cnt = torch.zeros(n * ((Co + 127) // 128), dtype=torch.int32, device=DEV)
+    pp = L.IgemmParams(out=ptr(o), pn_out=ptr(y), pn_gamma=ptr(gamma), pn_beta=ptr(beta), pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=groups,
+                       pn_silu=int(silu), pn_eps=eps, **ck)
+    assert lib.dc_igemm_pn_ok(pp) == 1
+    assert lib.dc_igemm_variant(pp).decode() == "conv3_halo<%s,8w,pn>" % {L.DC_F32: "f32", L.DC_BF16: "bf16", L.DC_F16: "f16"}[dt]
+    L.check(lib.dc_igemm(pp, L.stream_ptr()), "4x4 conv with wave-local GroupNorm")
+    torch.cuda.synchronize()
+    if raw:
+        assert torch.equal(o, o_ref)
+    assert torch.isfinite(y.float()).all()
+    idx = smap.long().cpu() if maps else torch.arange(n)
+    ref = F.conv2d(x[idx], w, b.cpu(), padding=1) + rv.cpu()[:, :, None, None]
+    if side:
+        ref = ref + torch.einsum("nchw,oc->nohw", xs[idx], ws2)
+    if res:
+        ref = ref + r.float().cpu()[idx].permute(0, 3, 1, 2)
+    yn = F.group_norm(ref, groups, gamma.cpu(), beta.cpu(), eps)
+    if silu:
+        yn = F.silu(yn)
+    assert maxrel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 3e-5, L.DC_BF16: 1.0e-2, L.DC_F16: 1.5e-3}[dt]
+    assert rel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 1e-5, L.DC_BF16: 4e-3, L.DC_F16: 6e-4}[dt]
+
+
 def test_groupnorm_span_kernel_opt_in():
     """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
     test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
