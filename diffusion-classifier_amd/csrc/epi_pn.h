@@ -216,8 +216,10 @@ __device__ __forceinline__ void epi_halo_pn(const IgemmArgs& a, f32x4 (&acc)[4][
     // still go to memory (plain stores) for any OTHER GroupNorm that reads this tensor's statistics later.
     if (lrp < 2) *reinterpret_cast<f32x4*>(grec) = rec;
     __syncthreads();                                         // every wave has left the tap loop: the scratch (a halo buffer) is free
+    DC_STAMP(4);
     if (lrp < 2) *reinterpret_cast<f32x4*>(c.scr + c.part * 16 + qpub) = rec;
     __syncthreads();
+    DC_STAMP(5);
     store_raw();
   } else {
     // ---- 1./2. publish, arrive, wait for the rest of the sample.  The hand-off is the counter form measured in MI355X_MICROARCH.md

@@ -23,9 +23,10 @@ def family(kernel):
     dt = "bf16" if ("DF16b" in k or "__bf16" in k) else ("f16" if ("DF16_" in k or "_Float16" in k) else "f32")
     ints = [int(v.replace("n", "-")) for v in re.findall(r"Li(n?\d+)E", k)] or [int(v) for v in re.findall(r"[<,](-?\d+)(?=[,>])", k)]
     if "conv3_halo_kernel" in k or "conv3_halo_pers_kernel" in k:     # <T, NW, (GN,) NTAP, ...>: the persistent form is the same family
+        pn = bool(re.search(r"Lb[01]ELb1EE", k) or re.search(r"(true|false),true>", k))      # <..., STG, PN = true>: producer-side GroupNorm
         if len(ints) > 1 and ints[1] == 4:                      # NTAP = 4: the four-phase upsample conv
-            return f"conv3_up4<{dt},{ints[0]}w>"
-        if re.search(r"Lb[01]ELb1EE", k) or re.search(r"(true|false),true>", k):   # <..., STG, PN = true>: producer-side GroupNorm
+            return f"conv3_up4<{dt},{ints[0]}w{',pn' if pn else ''}>"
+        if pn:
             return f"conv3_halo<{dt},{ints[0]}w,pn>"
         return f"conv3_halo<{dt},{ints[0]}w>"
     if "conv3_ws_kernel" in k or "conv3_wsp_kernel" in k:      # <T, GN>: wave-specialised halo conv (the persistent form is the same family)
