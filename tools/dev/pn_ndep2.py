@@ -1,4 +1,4 @@
-"""Developer probe: classify errors of rank 0's share of a 3-rank deal (config.simulate_rank) against the single-process errors."""
+"""Developer probe (round 4: found the launch-size dependence of the epilogue): classify errors of rank 0's share of a 3-rank deal (config.simulate_rank) against the single-process errors."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
