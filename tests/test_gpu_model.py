@@ -191,6 +191,29 @@ def test_producer_side_groupnorm_statistics_match_the_swept_plan(monkeypatch):
     assert relerr(outs[0], outs[1]) < 1e-5, relerr(outs[0], outs[1])
 
 
+def test_producer_normalised_plan_matches_the_plan_with_groupnorm_passes(monkeypatch):
+    """Producer-side GroupNorm (csrc/epi_pn.h, engine.PlanBuilder.pn_claim) against the round-3 plan (`DCAMD_NO_PN`: GroupNorm passes and
+    the wave-specialised conv): the same network, the same statistics records, only the place where the tensor is normalised differs.  f32:
+    rounding noise; the plan must really contain the three producer forms (4-wave exchange, upsample, 8-wave wave-local)."""
+    kw = dca.cifar10_unet_kwargs()
+    torch.manual_seed(19)
+    x, lam, emb = torch.randn(5, 3, 32, 32), torch.tensor([4.0, 0.5, -6.0, 1.0, 9.0]), torch.randn(5, 1, 128)
+    outs, fams = [], []
+    for on in (True, False):
+        if on:
+            monkeypatch.delenv("DCAMD_NO_PN", raising=False)
+        else:
+            monkeypatch.setenv("DCAMD_NO_PN", "1")
+        m, _ = make_pair(kw, seed=7)
+        m = m.to(DEV)
+        outs.append(m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).cpu())
+        plan = next(iter(m._plans.values()))
+        fams.append({mt.get("family", "") for mt in plan.pb.meta})
+    assert {"conv3_halo<f32,4w,pn>", "conv3_halo<f32,8w,pn>", "conv3_up4<f32,4w,pn>"} <= fams[0], fams[0]
+    assert not any(f.endswith(",pn>") for f in fams[1]) and any(f.startswith("conv3_ws<") for f in fams[1]), fams[1]
+    assert relerr(outs[0], outs[1]) < 1e-5, relerr(outs[0], outs[1])
+
+
 def test_one_token_cross_attention_shortcut_is_exact():
     """attn2 over a single class token == to_out(to_v(ctx)) for every query (what the engine uses)."""
     kw = dca.small_unet_kwargs()
