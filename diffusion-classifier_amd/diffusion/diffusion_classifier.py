@@ -544,7 +544,10 @@ class _HipRunner:
         sp = dict(plan=plan, score=score, ctl=ctl, pair_id=pair_id, words=words, n_bj=n_bj, k=k, U=U)
         dc._score_plans[key] = sp
         # each entry owns an arena, a workspace and an errors buffer in HBM, and n_bj follows the pair count (per rank, per stage, per
-        # last batch of a dataloader): keep the most recently used few (a multi-stage classify alternates between one plan per stage)
+        # last batch of a dataloader): keep the most recently used few (a multi-stage classify alternates between one plan per stage).
+        # (Scores that do not depend on n_bj — i.e. on the world size or the micro-batch split — rest on every kernel giving a sample the
+        # same bits wherever it sits in a launch and whichever tile shape the launch size selects; tests/test_gpu_dist.py and
+        # test_cfg2_full_grid_properties_at_bench_size hold that, and caught the one epilogue branch that did not in round 4.)
         cap = int(getattr(cfg, "score_plan_cache", None) or 6)
         while len(dc._score_plans) > max(cap, 1):
             del dc._score_plans[next(iter(dc._score_plans))]
