@@ -195,7 +195,20 @@ class DiffusionClassifier(nn.Module):
             classes = runner.stage_end(errors, ends[i + 1], cfg.n_keep_per_stage[i], last=i == cfg.n_stages - 1)
         assert classes.shape[1] == 1, "Only one class should be selected at the end of the classification process."
         out = classes[:, 0].to(device=x.device, dtype=torch.int64)
-        return (out, errors.cpu()) if return_errors else out
+        if return_errors:
+            err_host = errors.cpu()              # (synchronises: the cheap moment to look at the device-side failure counter)
+            self.check_device_errors()
+            return out, err_host
+        return out
+
+    def check_device_errors(self):
+        """Raise if a producer-side-GroupNorm launch (csrc/epi_pn.h) gave up waiting for the other workgroups of a sample since the last
+        check: its outputs were NaN-poisoned, so the scores of that call are invalid.  Synchronises with the device; called where the
+        host synchronises anyway — `classify(return_errors=True)`, the end of `evaluate`, bench.py, the smoke test."""
+        if torch.cuda.is_available() and hasattr(self.ema.ema_model, "make_plan"):
+            n = int(L.lib().dc_pn_timeouts())
+            if n:
+                raise L.DcamdError(f"{n} wave(s) timed out inside a producer-side GroupNorm launch: the results of this call are invalid")
 
     # ---- callers of the hot path (reference :532-578) ----------------------------------------
     @torch.no_grad()
@@ -213,6 +226,7 @@ class DiffusionClassifier(nn.Module):
             batches.append(batch)
             if stop_idx is not None and idx == stop_idx:
                 break
+        self.check_device_errors()
         return val_samples, batches, metrics
 
     def prefetch_to_device(self, loader, dev):

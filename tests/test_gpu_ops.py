@@ -1114,6 +1114,41 @@ def test_conv3x3_on_4x4_images_normalises_its_own_output_inside_the_wave(dt, cas
     assert rel(y.float().cpu(), yn.permute(0, 2, 3, 1)) < {L.DC_F32: 1e-5, L.DC_BF16: 4e-3, L.DC_F16: 6e-4}[dt]
 
 
+def test_a_wait_that_cannot_complete_times_out_counts_and_poisons_its_outputs():
+    """The bounded wait of csrc/epi_pn.h: a counter that can never reach its target (here: sample 1's arrival counter preset to
+    0xFFFFFFFF, so three of its four workgroups take tickets whose target is one arrival more than the launch delivers) must end in a
+    timeout — the launch returns after PN_TIMEOUT_TICKS (30 ms), `dc_pn_timeouts()` reports the waves (and clears the count), the
+    affected sample is NaN-poisoned and every other sample is untouched.  Never a hang."""
+    torch.manual_seed(79)
+    dt, n, H, W, Ci, Co = L.DC_BF16, 6, 32, 32, 64, 128
+    lib = L.lib()
+    x = nhwc(torch.randn(n, Ci, H, W), dt)
+    Wp = E.pack_conv3x3(torch.randn(Co, Ci, 3, 3) / (3 * Ci ** 0.5), dt, DEV)
+    b = torch.randn(Co).to(DEV)
+    gamma, beta = (torch.randn(Co) * 0.5 + 1).to(DEV), torch.randn(Co).to(DEV)
+
+    def launch(cnt):
+        y = torch.zeros(n, H, W, Co, dtype=TD[dt], device=DEV)
+        qs = torch.zeros(n, H * W // 128, Co // 4, 2, device=DEV)
+        p = L.IgemmParams(dtype=dt, taps=9, stride=1, upsample=0, n_img=n, Hin=H, Win=W, Hout=H, Wout=W, src0=ptr(x), C0=Ci, W=ptr(Wp), Cout=Co, tile_n=128,
+                          bias=ptr(b), out=None, out_dtype=dt, out_ld=Co, qstats=ptr(qs), pn_out=ptr(y), pn_gamma=ptr(gamma), pn_beta=ptr(beta),
+                          pn_cnt=ptr(cnt), pn_ld=Co, pn_groups=32, pn_silu=1, pn_eps=1e-5)
+        L.check(lib.dc_igemm(p, L.stream_ptr()), "pn conv")
+        torch.cuda.synchronize()
+        return y
+    assert lib.dc_pn_timeouts() == 0
+    good = launch(torch.zeros(n, dtype=torch.int32, device=DEV))
+    assert lib.dc_pn_timeouts() == 0 and torch.isfinite(good.float()).all()
+    cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+    cnt[1] = -1
+    bad = launch(cnt)
+    assert lib.dc_pn_timeouts() >= 3          # three workgroups x (one polling wave each)
+    assert lib.dc_pn_timeouts() == 0          # reading clears the count
+    assert torch.isnan(bad[1].float()).any()
+    keep = [0, 2, 3, 4, 5]
+    assert torch.equal(bad[keep], good[keep])
+
+
 def test_groupnorm_span_kernel_opt_in():
     """DCAMD_GN_SPAN=1 (read once per process): the short-span normalise sweep must pass the same quad-statistics GroupNorm
     test in ONE child interpreter — spans of 16 KiB, statistics folded from the records or from gn_qfold_kernel's output."""
