@@ -176,6 +176,7 @@ class PlanBuilder:
         if side is not None:
             meta["flops"] += 2.0 * M * side[0].C * Cout
             meta["K"] = kreal + side[0].C
+            meta["bytes"] += float(nsrc.get(side[0].dom, 1) * side[0].H * side[0].W * side[0].C * DT_SIZE[side[0].dt] + side[0].C * Cout * es)
         self._emit(L.OP_IGEMM, L.IgemmParams, f, [src0, src1, rowvec, gate, residual] + (list(gn[:2]) if gn else []) + ([side[0]] if side else []), [out] + ([qs] if qs else []), meta)
         if qstats and gn is None and (qs is not None or (taps == 9 and stride == 1 and not upsample and Hin == 4 and Win == 4)):
             out.prod = len(self.ops) - 1       # (4x4 images: no quad records, but the conv can still normalise its output inside the wave)
