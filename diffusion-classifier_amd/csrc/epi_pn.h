@@ -17,19 +17,21 @@
 //   3. every wave copies the sample's records of ITS 64 channels into LDS (16-byte `sc1` loads, two records per lane and load, all
 //      loads in flight together) and the 16 lanes of a row fold the groups of their two 8-channel runs together (pn_fold_row: the GroupNorm
 //      kernels' shifted one-pass form over the same records, the parts dealt to the lanes);
-//   4. raw store (if anyone reads the raw tensor), then y = act(v * a + b) in place and the normalised store.
+//   4. y = act(v * a + b) in place and the normalised store.  The raw tensor, where something reads it (a ResNet's shortcut, the transformer's
+//      residual), is stored between the arrival and the poll: its stores ride inside the counter's round trip.
+// A sample that IS one tile (16x16) exchanges nothing through memory: the two parts meet in LDS.  The four-phase upsample conv takes the
+// same path with the four phases of every low-resolution tile as the group.
 //
 // Forward progress: a workgroup waits only for workgroups of its own (sample, N tile), which the launch places on consecutive
 // positions of one XCD's dispatch queue (conv3_halo.hip, PN block order).  Workgroups are dispatched in index order, so when one member
 // of a group is resident every earlier group of that queue is resident or finished, and the members not yet dispatched are next in
 // line: they start as soon as ANY resident workgroup of an earlier, complete group retires — which those can always do.  (If the
-// hardware dealt blocks to XCDs in another way the members would merely sit further apart in the one global order; same argument.)  The host refuses groups larger
-// than a fraction of the chip's workgroup slots (dc_igemm_pn_ok).  The poll loop is bounded all the same (PN_TIMEOUT_TICKS of the
+// hardware dealt blocks to XCDs in another way the members would merely sit further apart in the one global order; same argument.)
+// The host refuses groups of more than 16 workgroups — a quarter of ONE XCD's 64 workgroup slots (dc_igemm_pn_ok).  The poll loop is bounded all the same (PN_TIMEOUT_TICKS of the
 // 100 MHz real-time counter): a wave that times out raises g_pn_timeouts (checked by the host, dc_pn_timeouts) and goes on with
 // whatever records are there — wrong numbers and an error, never a hang.
 #pragma once
 #include "igemm_epilogue.h"
-#include "gn_fold.h"
 
 #ifndef PN_TIMEOUT_TICKS
 #define PN_TIMEOUT_TICKS 3000000ull          // 30 ms at 100 MHz; a real wait is the dispatch skew inside one group (microseconds)

@@ -1,6 +1,6 @@
-// gn_fold.h — the (count, mean, M2) arithmetic of GroupNorm statistics shared by norms.hip (the GroupNorm kernels) and the
-// producer-side normalisation in conv3_halo.hip's epilogue (epi_pn.h): both fold the same quad records in the same order with the
-// same instructions, so a tensor normalised by its producer carries exactly the affine the GroupNorm kernels would have applied.
+// gn_fold.h — the (count, mean, M2) arithmetic of the GroupNorm kernels (norms.hip): Chan's update and the one-pass fold of a producer's
+// quad records.  (The producer-side GroupNorm of csrc/epi_pn.h folds the same records with the same shifted one-pass form, its parts dealt
+// to the 16 lanes of a row: pn_fold_row there.)
 #pragma once
 #include "common.h"
 
