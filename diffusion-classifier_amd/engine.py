@@ -18,7 +18,6 @@ connections are never concatenated in memory.
 PyTorch is used for device memory and streams only.
 """
 import ctypes as C
-import math
 
 import torch
 
