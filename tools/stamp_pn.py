@@ -2,15 +2,18 @@
 """Diagnostic (developer tool): build libdcamd with -DDC_STAMPS into gpurun_out/ and print where a producer-normalising conv3_halo
 workgroup (csrc/epi_pn.h) spends its cycles (s_memtime stamps per workgroup, medians; shares only, never a timing claim), next to the
 plain conv of the same shape.  env: HW (32), N (2000), CI / CO (128), RES (1), RAW (1: also store the raw output), ABLS (0,16,32,48:
-16 = do not wait for the sample's other tiles, 32 = no SiLU; results wrong on purpose)."""
+16 = do not wait for the sample's other tiles, 32 = no SiLU; results wrong on purpose), PLAIN_ABLS (0), STAMP_LIB (a prebuilt -DDC_STAMPS library)."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "libdcamd_stamps.so")
 src = os.path.join(ROOT, "diffusion-classifier_amd", "csrc")
 srcs = [f for f in sorted(os.listdir(src)) if f.endswith(".hip")]
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDC_STAMPS", "-shared", "-Wno-unused-function",
-                f"-I{ROOT}/include", "-o", out] + [os.path.join(src, f) for f in srcs], check=True)
+if os.environ.get("STAMP_LIB"):        # a -DDC_STAMPS library built beforehand (e.g. into tools/dev/_build/, which travels to the GPU box)
+    out = os.path.abspath(os.environ["STAMP_LIB"])
+else:
+  subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDC_STAMPS", "-shared", "-Wno-unused-function",
+                  f"-I{ROOT}/include", "-o", out] + [os.path.join(src, f) for f in srcs], check=True)
 os.environ["DCAMD_LIB"] = out
 import torch
 import diffusion_classifier_amd as dca
@@ -41,7 +44,7 @@ lib.dc_debug_set_halo_abl.argtypes = [ctypes.c_int]
 for name, p, names in (("plain", plain, ["setup", "mainloop", "epi:bias", "epi:loads0", "epi:math", "epi:stats+stores"]),
                        ("pn", pn, ["setup", "mainloop", "epi:bias+residual", "stats+publish", "wait", "load+fold", "stores"])):
     print("kernel:", lib.dc_igemm_variant(p).decode())
-    for abl in ([0] if name == "plain" else [int(v) for v in os.environ.get("ABLS", "0,16,32,48").split(",")]):
+    for abl in ([int(v) for v in os.environ.get("PLAIN_ABLS", "0").split(",")] if name == "plain" else [int(v) for v in os.environ.get("ABLS", "0,16,32,48").split(",")]):
         lib.dc_debug_set_halo_abl(abl)
         lib.dc_debug_set_stamps(None)
         for _ in range(2):
