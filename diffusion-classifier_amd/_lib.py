@@ -9,10 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCAMD_LIB") or os.path.join(_HERE, "libdcamd.so")   # DCAMD_LIB: diagnostic builds only
 
-ABI_VERSION = 3      # include/dcamd.h DC_ABI_VERSION
+ABI_VERSION = 4      # include/dcamd.h DC_ABI_VERSION
 DC_F32, DC_BF16, DC_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GELU_TANH = 0, 1, 2, 3
-OP_QSAMPLE, OP_SINUSOID, OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_EPS_MSE = 1, 2, 3, 4, 5, 6, 7
+OP_QSAMPLE, OP_SINUSOID, OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_EPS_MSE, OP_TBLOCK_FRONT = 1, 2, 3, 4, 5, 6, 7, 8
 
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 
@@ -66,6 +66,13 @@ class AttentionParams(C.Structure):
                 ("ld_qkv", i32), ("ld_out", i32), ("scale", f32)]
 
 
+class TblockFrontParams(C.Structure):
+    _fields_ = [("x", vp), ("Wp", vp), ("bp", vp), ("ln_g", vp), ("ln_b", vp), ("Wqkv", vp), ("Wo", vp), ("bo", vp),
+                ("rowvec", vp), ("rowvec_map", vp), ("out", vp),
+                ("dtype", i32), ("n", i32), ("L", i32), ("C", i32), ("heads", i32), ("ldx", i32), ("ld_out", i32), ("rowvec_ld", i32),
+                ("ln_eps", f32), ("scale", f32)]
+
+
 class EpsMseParams(C.Structure):
     _fields_ = [("pred", vp), ("eps", vp), ("x", vp), ("alpha", vp), ("sigma", vp),
                 ("bj_of_unit", vp), ("img_of_bj", vp), ("out_index", vp),
@@ -85,7 +92,7 @@ class Op(C.Structure):
 # every symbol include/dcamd.h declares (tests check that the library exports all of them)
 EXPORTS = ["dc_abi_version", "dc_last_error", "dc_arch", "dc_qsample", "dc_philox_normal", "dc_sinusoid",
            "dc_igemm", "dc_igemm_cout_pad", "dc_igemm_variant", "dc_igemm_gn_fusable", "dc_igemm_side_ok", "dc_igemm_ln_ok", "dc_igemm_qstats_parts", "dc_igemm_up4_ok", "dc_igemm_pn_ok", "dc_pn_timeouts", "dc_groupnorm", "dc_groupnorm_ws_floats", "dc_groupnorm_splits",
-           "dc_layernorm", "dc_attention", "dc_eps_mse", "dc_ddpm_step", "dc_haar_dwt2", "dc_haar_idwt2", "dc_stage_topk", "dc_reduce_argmin", "dc_stage_maps", "dc_run_plan", "dc_run_plan_timed",
+           "dc_layernorm", "dc_attention", "dc_tblock_front", "dc_tblock_front_ok", "dc_eps_mse", "dc_ddpm_step", "dc_haar_dwt2", "dc_haar_idwt2", "dc_stage_topk", "dc_reduce_argmin", "dc_stage_maps", "dc_run_plan", "dc_run_plan_timed",
            "dc_packed_bytes", "dc_pack_weights_matrix", "dc_pack_weights_conv3x3", "dc_pack_weights_up4", "dc_pack_weights_geglu",
            "dc_fold_layernorm_bias", "dc_workspace_bytes_groupnorm", "dc_workspace_bytes_igemm", "dc_workspace_bytes_attention",
            "dc_workspace_bytes_layernorm"]
@@ -116,6 +123,7 @@ def lib():
                        ("dc_groupnorm", [C.POINTER(GroupnormParams), vp]),
                        ("dc_layernorm", [C.POINTER(LayernormParams), vp]),
                        ("dc_attention", [C.POINTER(AttentionParams), vp]),
+                       ("dc_tblock_front", [C.POINTER(TblockFrontParams), vp]),
                        ("dc_eps_mse", [C.POINTER(EpsMseParams), vp]),
                        ("dc_ddpm_step", [C.POINTER(DdpmStepParams), vp]),
                        ("dc_run_plan", [C.POINTER(Op), i32, vp]),
@@ -142,6 +150,8 @@ def lib():
     L.dc_igemm_up4_ok.restype = C.c_int32
     L.dc_igemm_pn_ok.argtypes = [C.POINTER(IgemmParams)]
     L.dc_igemm_pn_ok.restype = C.c_int32
+    L.dc_tblock_front_ok.argtypes = [C.POINTER(TblockFrontParams)]
+    L.dc_tblock_front_ok.restype = C.c_int32
     L.dc_pn_timeouts.argtypes = []
     L.dc_pn_timeouts.restype = C.c_int32
     L.dc_igemm_side_ok.argtypes = [C.POINTER(IgemmParams)]

@@ -70,6 +70,7 @@ static int run_one(const dc_op* ops, int i, dc_stream s) {
       case DC_OP_GROUPNORM: rc = dc_groupnorm(static_cast<const dc_groupnorm_params*>(ops[i].params), s); break;
       case DC_OP_LAYERNORM: rc = dc_layernorm(static_cast<const dc_layernorm_params*>(ops[i].params), s); break;
       case DC_OP_ATTENTION: rc = dc_attention(static_cast<const dc_attention_params*>(ops[i].params), s); break;
+      case DC_OP_TBLOCK_FRONT: rc = dc_tblock_front(static_cast<const dc_tblock_front_params*>(ops[i].params), s); break;
       case DC_OP_EPS_MSE: rc = dc_eps_mse(static_cast<const dc_eps_mse_params*>(ops[i].params), s); break;
       default: dc_set_error("dc_run_plan: op %d has unknown kind %d", i, ops[i].kind); return DC_ERR_ARG;
     }

@@ -333,6 +333,29 @@ class PlanBuilder:
                         bytes=4.0 * self.n[q.dom] * Lq * q.C * DT_SIZE[q.dt]))
         return out
 
+    def tblock_front_ok(self, x, heads):
+        """Can ONE launch take proj_in -> LayerNorm -> q/k/v -> attention -> to_out of this block input (dc_tblock_front_ok)?"""
+        fn = getattr(L.lib(), "dc_tblock_front_ok", None)
+        if fn is None:
+            return False
+        p = L.TblockFrontParams(dtype=x.dt, n=self.n[x.dom], L=x.H * x.W, C=x.C, heads=heads, ldx=x.ld, ld_out=x.C)
+        return int(fn(p)) == 1
+
+    def tblock_front(self, name, x, Wp, bp, ln_g, ln_b, Wqkv, Wo, bo, rowvec, heads, eps):
+        """out = to_out(attention(LayerNorm(h))) + bo + rowvec + h with h = proj_in(x) + bp, one workgroup per sample (dc_tblock_front)."""
+        assert rowvec is None or self._dom(x, rowvec) == x.dom, "the class vector must not widen the block's domain"
+        dom, Lq, Cc = x.dom, x.H * x.W, x.C
+        d = Cc // heads
+        out = self.tensor(name, dom, x.H, x.W, Cc, x.dt)
+        f = dict(x=x, Wp=Wp, bp=bp, ln_g=ln_g, ln_b=ln_b, Wqkv=Wqkv, Wo=Wo, bo=bo, rowvec=rowvec, rowvec_map=self._map(rowvec, dom),
+                 rowvec_ld=rowvec.ld if rowvec is not None else 0, out=out, dtype=x.dt, n=self.n[dom], L=Lq, C=Cc, heads=heads,
+                 ldx=x.ld, ld_out=out.ld, ln_eps=float(eps), scale=float(d) ** -0.5)
+        M, es = self.n[dom] * Lq, DT_SIZE[x.dt]
+        self._emit(L.OP_TBLOCK_FRONT, L.TblockFrontParams, f, [x, rowvec], [out],
+                   dict(name=name, family="tblock_front", flops=2.0 * M * Cc * 5 * Cc + 4.0 * self.n[dom] * heads * Lq * Lq * d,
+                        bytes=float(2 * M * Cc * es + 5 * Cc * Cc * es), M=M, N=Cc, K=Cc))
+        return out
+
     def sinusoid(self, name, lam, dim, flip, shift):
         out = self.tensor(name, lam.dom, 1, 1, dim, L.DC_F32)
         f = dict(lam=lam, out=out, n=self.n[lam.dom], dim=dim, flip_sin_to_cos=int(flip), freq_shift=float(shift))
@@ -696,6 +719,8 @@ class UNetPlan:
         use_qs = os.environ.get("DCAMD_NO_QSTATS") is None
         use_up4 = os.environ.get("DCAMD_NO_UP4") is None
         fold_ln = os.environ.get("DCAMD_NO_LN_FOLD") is None
+        # the attention half of a transformer block (proj_in ... to_out) as one launch where libdcamd serves the shape (tblock.hip)
+        fuse_tb = os.environ.get("DCAMD_NO_TBLOCK") is None
         # GroupNorm(+SiLU) applied by the consuming 3x3 conv's loader waves (conv3_ws.hip) from the producer's quad records: no
         # GroupNorm launch, the normalised tensor never exists (DCAMD_NO_GN_WS: the GroupNorm pass + the plain conv, for A/B runs)
         fuse_ws = os.environ.get("DCAMD_NO_GN_WS") is None and use_qs
@@ -837,6 +862,12 @@ class UNetPlan:
             h = pb.pn_claim(x, pb.const(P[key + ".norm.g"]), pb.const(P[key + ".norm.b"]), G, 1e-6, False)
             if h is None:
                 h = pb.groupnorm(key + ".gn", x, pb.const(P[key + ".norm.g"]), pb.const(P[key + ".norm.b"]), G, 1e-6, False)
+            if fuse_tb and h.dom == pb._dom(h, cvec[key]) and pb.tblock_front_ok(h, heads):
+                # proj_in -> LayerNorm -> q/k/v -> attention -> to_out + class vector + residual in ONE launch, the sample on chip
+                h = pb.tblock_front(tbk + ".front", h, pb.const(P[key + ".proj_in.w"]), pb.const(P[key + ".proj_in.b"]),
+                                    pb.const(P[tbk + ".norm1.g"]), pb.const(P[tbk + ".norm1.b"]), pb.const(P[tbk + ".qkv.w"]),
+                                    pb.const(P[tbk + ".attn1.to_out.0.w"]), pb.const(P[tbk + ".attn1.to_out.0.b"]), cvec[key], heads, 1e-5)
+                return transformer_back(key, tbk, x, h, Cc)
             h = pb.igemm(key + ".proj_in", h, pb.const(P[key + ".proj_in.w"]), Cc, bias=pb.const(P[key + ".proj_in.b"]))
             # LayerNorm folded into the consuming GEMM where the activation-stationary kernel can standardise the rows itself
             # (gamma into W's columns, beta into the bias: UNetWeights.fold_layernorms): no LayerNorm launch, no normalised tensor
@@ -846,6 +877,9 @@ class UNetPlan:
             o = pb.attention(tbk + ".attn1", qkv.view(0, Cc), qkv.view(Cc, Cc), qkv.view(2 * Cc, Cc), heads)
             h = pb.igemm(tbk + ".attn_out", o, pb.const(P[tbk + ".attn1.to_out.0.w"]), Cc,
                          bias=pb.const(P[tbk + ".attn1.to_out.0.b"]), rowvec=cvec[key], residual=h)
+            return transformer_back(key, tbk, x, h, Cc)
+
+        def transformer_back(key, tbk, x, h, Cc):
             if fold_ln and pb.ln_ok(h, 8 * Cc, L.ACT_GEGLU):
                 weights.fold_layernorms(tbk)
                 f = pb.igemm(tbk + ".geglu", h, pb.const(P[tbk + ".ff.net.0.proj.wf"]), 8 * Cc,

@@ -38,7 +38,7 @@ extern "C" {
 
 /* 2: qstats records are (mean, M2) sets (version 1: sum, sum of squares) and qparts must divide HW
  * 3: dc_ddpm_step_params.one_plus_w; dc_attention requires scale > 0; dc_igemm_params.pn_* (producer-side GroupNorm) */
-#define DC_ABI_VERSION 3
+#define DC_ABI_VERSION 4
 
 typedef void* dc_stream; /* hipStream_t */
 
@@ -239,6 +239,27 @@ typedef struct {
 int dc_attention(const dc_attention_params* p, dc_stream s);
 int64_t dc_workspace_bytes_attention(const dc_attention_params* p);
 
+/* ---------------------------------------------------------------- transformer block, attention half --- */
+/* One launch for the self-attention half of a UNet transformer block (the backbone behind /root/reference/nets/unet.py:186-195:
+ * Transformer2DModel.proj_in -> BasicTransformerBlock.norm1 -> attn1 (to_q/k/v, softmax, to_out) -> + attn2's class vector -> residual):
+ *   h = x Wp^T + bp;  hn = LayerNorm(h; eps) * ln_g + ln_b;  q | k | v = hn Wqkv^T (rows [0,C) q, [C,2C) k, [2C,3C) v; head i = channels
+ *   [i d, (i+1) d), d = C / heads);  o = softmax(q k^T * scale) v per (sample, head);  out = ((o Wo^T + bo) + rowvec[rowvec_map[n]]) + h.
+ * x [n, L, ldx], out [n, L, ld_out] in `dtype` (16-bit); Wp / Wo [C][C], Wqkv [3C][C] packed as dc_igemm takes them (dc_pack_weights_matrix,
+ * tile_n 128); biases, LayerNorm affine and rowvec fp32.  h, hn, q, k, v, p, o are rounded to `dtype` where the separate launches
+ * (dc_igemm, dc_layernorm, dc_attention) store them, so results agree with that chain to accumulation order.
+ * Shapes: dc_tblock_front_ok() (L = 64, C = 256, heads = 4 or 8 today); anything else returns DC_ERR_SHAPE. */
+typedef struct {
+  const void* x; const void* Wp; const float* bp;
+  const float* ln_g; const float* ln_b;
+  const void* Wqkv; const void* Wo; const float* bo;
+  const float* rowvec; const int32_t* rowvec_map;
+  void* out;
+  int32_t dtype, n, L, C, heads, ldx, ld_out, rowvec_ld;
+  float ln_eps, scale;
+} dc_tblock_front_params;
+int dc_tblock_front(const dc_tblock_front_params* p, dc_stream s);
+int32_t dc_tblock_front_ok(const dc_tblock_front_params* p);     /* 1: the shape / dtype is served (pointers are not looked at) */
+
 /* ---------------------------------------------------------------- eps-MSE -------- */
 /* err[u] = (|| eps_hat_u - eps_{bj(u)} ||_2)^2 over C*H*W   (reference :706-711)
  * pred [n_units, H, W, ld] f32 NHWC; eps [n_bj,C,H,W], x [n_img,C,H,W] f32 NCHW.
@@ -291,7 +312,7 @@ int dc_stage_maps(const int32_t* keep, int32_t BS, int32_t C, int32_t T, int32_t
 
 /* ---------------------------------------------------------------- plan ----------- */
 typedef enum { DC_OP_QSAMPLE = 1, DC_OP_SINUSOID = 2, DC_OP_IGEMM = 3, DC_OP_GROUPNORM = 4,
-               DC_OP_LAYERNORM = 5, DC_OP_ATTENTION = 6, DC_OP_EPS_MSE = 7 } dc_op_kind;
+               DC_OP_LAYERNORM = 5, DC_OP_ATTENTION = 6, DC_OP_EPS_MSE = 7, DC_OP_TBLOCK_FRONT = 8 } dc_op_kind;
 typedef struct { int32_t kind; int32_t pad_; const void* params; } dc_op;
 /* Launch ops[0..n) in order on the stream; stops at the first failure and returns its
  * status (failed index via dc_last_error text). */

@@ -1499,3 +1499,72 @@ def test_weight_packers_match_their_documented_layouts(dt):
     gp = L.GroupnormParams(n=3, HW=64, C=128, C1=0, groups=32, splits=0)
     assert lib.dc_workspace_bytes_groupnorm(gp) == 4 * lib.dc_groupnorm_ws_floats(3, 32, lib.dc_groupnorm_splits(3, 64, 128))
     assert lib.dc_workspace_bytes_igemm(L.IgemmParams()) == 0 and lib.dc_workspace_bytes_attention(L.AttentionParams()) == 0
+
+
+@pytest.mark.parametrize("dt", [L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("n,heads", [(1, 8), (5, 4), (300, 8)])
+def test_tblock_front_matches_the_separate_launches(dt, n, heads):
+    """The attention half of a transformer block in one launch (dc_tblock_front: proj_in -> LayerNorm -> q/k/v -> attention -> to_out +
+    class vector + residual, 64 tokens x 256 channels) against (a) the chain of separate C-ABI launches it replaces and (b) a plain
+    PyTorch fp32 reference with the same 16-bit rounding points.  The fused kernel rounds where the chain stores, so only accumulation
+    order differs: bound = a few output ulps (bf16 2^-8, f16 2^-11 relative) on values of order 1."""
+    torch.manual_seed(40 + n)
+    lib = L.lib()
+    Lq, Cc, ncls = 64, 256, 3
+    td = TD[dt]
+    q = lambda t: t.to(td).float()
+    x = q(torch.randn(n, Lq, Cc))
+    Wp, Wqkv, Wo = (q(torch.randn(r, Cc) / Cc ** 0.5) for r in (Cc, 3 * Cc, Cc))
+    bp, bo = 0.1 * torch.randn(Cc), 0.1 * torch.randn(Cc)
+    g, b = 1 + 0.2 * torch.randn(Cc), 0.1 * torch.randn(Cc)
+    cvec = torch.randn(ncls, Cc)
+    cmap = torch.randint(0, ncls, (n,), dtype=torch.int32)
+    # (b) fp32 reference, rounding where the chain stores
+    h = q(x @ Wp.T + bp)
+    hn = q(F.layer_norm(h, (Cc,), g, b, 1e-5))
+    qkv = q(hn @ Wqkv.T)
+    sh = lambda z: z.view(n, Lq, heads, Cc // heads).transpose(1, 2)
+    sc = (sh(qkv[..., :Cc]) @ sh(qkv[..., Cc:2 * Cc]).transpose(-1, -2)) * (Cc // heads) ** -0.5
+    p_ = torch.softmax(sc, -1)
+    o = q((p_ @ sh(qkv[..., 2 * Cc:])).transpose(1, 2).reshape(n, Lq, Cc))
+    ref = ((o @ Wo.T + bo) + cvec[cmap.long()][:, None, :]) + h
+    # device operands
+    xd = x.to(td).to(DEV)
+    Wpd, Wqd, Wod = (E.pack_matrix(w, dt, DEV) for w in (Wp, Wqkv, Wo))
+    f32 = lambda t: t.float().contiguous().to(DEV)
+    bpd, bod, gd, bd, cvd, cmd = f32(bp), f32(bo), f32(g), f32(b), f32(cvec), cmap.to(DEV)
+    out = torch.full((n, Lq, Cc), float("nan"), dtype=td, device=DEV)
+    tp = L.TblockFrontParams(x=ptr(xd), Wp=ptr(Wpd), bp=ptr(bpd), ln_g=ptr(gd), ln_b=ptr(bd), Wqkv=ptr(Wqd), Wo=ptr(Wod), bo=ptr(bod),
+                             rowvec=ptr(cvd), rowvec_map=ptr(cmd), out=ptr(out), dtype=dt, n=n, L=Lq, C=Cc, heads=heads, ldx=Cc, ld_out=Cc,
+                             rowvec_ld=Cc, ln_eps=1e-5, scale=(Cc // heads) ** -0.5)
+    assert lib.dc_tblock_front_ok(tp) == 1
+    L.check(lib.dc_tblock_front(tp, L.stream_ptr()), "dc_tblock_front")
+    torch.cuda.synchronize()
+    # (a) the chain of separate launches
+    M = n * Lq
+    gemm = lambda src, W, Cout, **kw: run_igemm(dtype=dt, taps=1, stride=1, upsample=0, n_img=n, Hin=8, Win=8, Hout=8, Wout=8, src0=ptr(src), C0=Cc,
+                                                ld0=Cc, W=ptr(W), Cout=Cout, tile_n=128, out_dtype=dt, out_ld=Cout, **kw)
+    hd = torch.empty(M, Cc, dtype=td, device=DEV)
+    gemm(xd, Wpd, Cc, bias=ptr(bpd), out=ptr(hd))
+    hnd = torch.empty_like(hd)
+    L.check(lib.dc_layernorm(L.LayernormParams(x=ptr(hd), y=ptr(hnd), dtype=dt, out_dtype=dt, rows=M, C=Cc, rows_per_sample=Lq, eps=1e-5,
+                                               gamma=ptr(gd), beta=ptr(bd)), L.stream_ptr()), "ln")
+    qkvd = torch.empty(M, 3 * Cc, dtype=td, device=DEV)
+    gemm(hnd, Wqd, 3 * Cc, out=ptr(qkvd))
+    od = torch.empty_like(hd)
+    L.check(lib.dc_attention(L.AttentionParams(q=qkvd.data_ptr(), k=qkvd.data_ptr() + 2 * Cc, v=qkvd.data_ptr() + 4 * Cc, out=ptr(od), dtype=dt, n=n,
+                                               L=Lq, heads=heads, d=Cc // heads, ld_qkv=3 * Cc, ld_out=Cc, scale=(Cc // heads) ** -0.5), L.stream_ptr()), "attn")
+    chain = torch.empty_like(hd)
+    gemm(od, Wod, Cc, bias=ptr(bod), rowvec=ptr(cvd), rowvec_map=ptr(cmd), rowvec_ld=Cc, residual=ptr(hd), res_dtype=dt, res_ld=Cc, out=ptr(chain))
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    ulp = 2.0 ** -8 if dt == L.DC_BF16 else 2.0 ** -11
+    scale_ = ref.abs().max().item()
+    e_ref = (got - ref).abs().max().item() / scale_
+    e_chain = (got - chain.float().cpu().view(n, Lq, Cc)).abs().max().item() / scale_
+    print(f"dc_tblock_front n={n} heads={heads} dt={dt}: max err / max|ref| vs fp32 reference {e_ref:.2e}, vs the chain of launches {e_chain:.2e} (bound {3 * ulp:.2e})")
+    assert e_ref < 3 * ulp and e_chain < 3 * ulp
+    # shapes it does not serve are refused, not mis-computed
+    bad = L.TblockFrontParams(dtype=dt, n=n, L=16, C=512, heads=8, ldx=512, ld_out=512)
+    assert lib.dc_tblock_front_ok(bad) == 0
