@@ -12,17 +12,26 @@
 //   * two LDS images [64 tokens][C] (row pitch + 16 B: the 16 rows of a fragment read cover the 64 banks once) hold x -> hn -> o and
 //     h -> out; a sample enters and leaves HBM once, as whole rows;
 //   * wave w owns output channels 64 w .. + 63 of EVERY GEMM (one head of 64 channels or two of 32): its weight rows come straight from L2 into registers as
-//     MFMA A-operand fragments (16 B per lane, three k-steps in flight), never through LDS — no other wave of the workgroup wants them;
+//     MFMA A-operand fragments (16 B per lane, two k-steps ahead), never through LDS — no other wave of the workgroup wants them;
 //   * every GEMM is D[cout][token] = W[cout][:] . X[token][:] (16x16x32 MFMA, A = W rows, B = X rows from the LDS image), so a lane
 //     ends up with 4 consecutive channels of one token.  Packed in pairs of channel fragments those ARE the operands of the score
 //     product (the k order inside an MFMA is free as long as A and B agree): S^T = K Q^T needs no LDS round trip.  V is computed with
 //     the operands swapped (D[token][d]): a lane then holds 4 consecutive KEYS of one d column — the A operand of O^T += V^T P^T
 //     beside the packed P^T fragments of the softmax (the trick of attn_flash_t_kernel, without its transposed LDS reads).
-// Two workgroups per CU (66 KiB of LDS, <= 256 registers): one's LayerNorm / softmax / row stores run under the other's MFMAs.
+// Two workgroups per CU (71 KiB of LDS, <= 256 registers): one's LayerNorm / softmax / row stores run under the other's MFMAs.
 // Rounding points are those of the separate launches (h, hn, q, k, v, p, o and out rounded to the 16-bit type where they were stored).
 #include <stdlib.h>
 #include <utility>
 #include "igemm_common.h"
+
+#ifdef DC_STAMPS
+// diagnostic build only (tools/stamp_tblock.py): s_memtime stamps of thread 0 of every workgroup, 16 per workgroup; never compiled into the shipped library
+static __device__ unsigned long long* g_tb_stamps;
+extern "C" void dc_debug_set_tb_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tb_stamps), &p, sizeof(p)); }
+#define TB_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && g_tb_stamps) g_tb_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TB_STAMP(k) do {} while (0)
+#endif
 
 namespace {
 struct TbArgs {
@@ -81,17 +90,26 @@ __device__ __forceinline__ void tb_lds_barrier() {
 }
 }  // namespace
 
-template <typename T, int D>                      // D: channels per head (32 or 64); a wave's 64 channels are 64 / D whole heads
+// D: channels per head (32 or 64); a wave's 64 channels are 64 / D whole heads.
+// (Two samples per eight-wave workgroup — waves w and w + 4 asking for the same weight fragments, the second request served by the CU's
+//  L1 — was built and measured: 0.75 against 0.65 ms per 8000 samples.  One workgroup per CU runs its eight waves through the same
+//  phase at the same time; two independent ones hide each other's LayerNorm / softmax / row stores.)
+template <typename T, int D>
 __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
   constexpr int C = 256, L = 64, PB = C * 2 + 16;     // channels, tokens, LDS row pitch in bytes
   constexpr int NKC = C / 32, NST = 5 * NKC;          // k-steps per GEMM; steps of the five GEMMs: proj_in, K, V, Q, to_out
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const img0 = smem;                            // x -> hn -> o
-  char* const img1 = smem + L * PB;                   // h -> out
+  char* const img1 = img0 + L * PB;                   // h -> out
+  // fp32 vectors every wave reads in its epilogues, staged once (fetched per use they were 2.5 - 10 k cycles of exposed global-load
+  // latency in front of the LayerNorm and the last epilogue): proj_in bias | LayerNorm gamma | beta | to_out bias | the sample's class vector
+  float* const tab = reinterpret_cast<float*>(smem + 2 * L * PB);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int n = blockIdx.x;
+  TB_STAMP(0);
+  const int rvrow = a.rowvec_map ? a.rowvec_map[n] : n;        // (first: the class vector's load depends on it)
 
   // ---- the sample's rows into image 0 (16-byte pieces, whole rows) ----
   {
@@ -108,6 +126,11 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
       *reinterpret_cast<chunk16*>(img0 + row * PB + c * 16) = v[i];
     }
   }
+  tab[t] = a.bp[t];
+  tab[C + t] = a.ln_g[t];
+  tab[2 * C + t] = a.ln_b[t];
+  tab[3 * C + t] = a.bo ? a.bo[t] : 0.f;
+  tab[4 * C + t] = a.rowvec ? a.rowvec[(size_t)rvrow * a.rowvec_ld + t] : 0.f;
 
   // ---- weight stream: step s = (GEMM g = s / NKC, k-chunk s % NKC); the lane's fragment of channel block cf is 16 bytes of row
   // row0(g) + 16 cf + lr at k = 32 kc + 8 lq ----
@@ -115,17 +138,21 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
   const T* const Wq = reinterpret_cast<const T*>(a.Wqkv);
   const T* const Wo = reinterpret_cast<const T*>(a.Wo);
   const int wrow = (wave * 64 + lr) * C + lq * 8;
-  chunk16 wf[3][4];
+  // two k-steps ahead (measured: 3 and 4 steps ahead, and fetching k-steps in pairs so that both halves of a 128-byte line are asked for
+  // back to back, all run the launch in the same time +- 1 % — the GEMM phases sit at the ~26 B per cycle and CU that L2-resident vector
+  // loads deliver with every CU streaming, whatever is in flight: DESIGN 9)
+  constexpr int PD = 2, WR = PD + 1;
+  chunk16 wf[WR][4];
   auto issue = [&](auto sc) {
     constexpr int s = decltype(sc)::value, g = s / NKC, kc = s % NKC;
     const T* wb = g == 0 ? Wp : (g == 4 ? Wo : Wq + (g == 1 ? C * C : (g == 2 ? 2 * C * C : 0)));
     wb += wrow + kc * 32;
 #pragma unroll
-    for (int cf = 0; cf < 4; ++cf) wf[s % 3][cf] = *reinterpret_cast<const chunk16*>(wb + cf * 16 * C);
+    for (int cf = 0; cf < 4; ++cf) wf[s % WR][cf] = *reinterpret_cast<const chunk16*>(wb + cf * 16 * C);
   };
-  issue(std::integral_constant<int, 0>{});
-  issue(std::integral_constant<int, 1>{});
+  tb_static_for<PD>([&](auto sc) { issue(sc); });
   __syncthreads();
+  TB_STAMP(1);
 
   const uint32_t xoff = lr * PB + lq * 16;            // fragment read: row 16 tf + lr, bytes 64 kc + 16 lq
   const float sc2 = a.scale * 1.4426950408889634f;
@@ -140,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (s + 2 < NST) issue(std::integral_constant<int, s + 2>{});
-    __builtin_amdgcn_sched_barrier(0);          // the loads stay HERE, two steps ahead of their MFMAs (hipcc otherwise sinks each to its first use)
+    if constexpr (s + PD < NST) issue(std::integral_constant<int, s + PD>{});
+    __builtin_amdgcn_sched_barrier(0);          // the loads stay HERE, ahead of their MFMAs (hipcc otherwise sinks each to its first use)
     chunk16 xf[4];
 #pragma unroll
     for (int tf = 0; tf < 4; ++tf) xf[tf] = *reinterpret_cast<const chunk16*>(img0 + xoff + tf * 16 * PB + kc * 64);
@@ -149,17 +176,18 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
     for (int cf = 0; cf < 4; ++cf)
 #pragma unroll
       for (int tf = 0; tf < 4; ++tf)
-        acc[cf][tf] = g == 2 ? Mma<T>::run(xf[tf], wf[s % 3][cf], acc[cf][tf])      // V: rows = tokens, column = d
-                             : Mma<T>::run(wf[s % 3][cf], xf[tf], acc[cf][tf]);     // rows = channels, column = token
+        acc[cf][tf] = g == 2 ? Mma<T>::run(xf[tf], wf[s % WR][cf], acc[cf][tf])      // V: rows = tokens, column = d
+                             : Mma<T>::run(wf[s % WR][cf], xf[tf], acc[cf][tf]);     // rows = channels, column = token
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (kc != NKC - 1) return;
+    TB_STAMP(2 + 2 * g);                         // GEMM g's MFMAs issued: stamps 2, 4, 6, 8, 10
 
     if constexpr (g == 0) {
       // ---- h = proj_in + bias -> image 1 (rounded), then LayerNorm of its rows -> image 0 ----
 #pragma unroll
       for (int cf = 0; cf < 4; ++cf) {
         const int c = wave * 64 + cf * 16 + lq * 4;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(tab + c);
 #pragma unroll
         for (int tf = 0; tf < 4; ++tf) {
           f32x4 v = acc[cf][tf];
@@ -198,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
           const int ch = (part + 4 * k) * 8;
 #pragma unroll
           for (int e4 = 0; e4 < 8; e4 += 4) {
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + ch + e4);
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + ch + e4);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(tab + C + ch + e4);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(tab + 2 * C + ch + e4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float x = (v[k][e4 + e] - mean) * rstd;
@@ -210,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
         }
       }
       tb_lds_barrier();
+      TB_STAMP(3);
     } else if constexpr (g == 1) {
 #pragma unroll
       for (int tf = 0; tf < 4; ++tf)
@@ -272,15 +301,14 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
         }
       }
       tb_lds_barrier();
+      TB_STAMP(9);
     } else {
       // ---- out = (to_out + bias) + rowvec + h, back into this wave's own columns of image 1 ----
-      const float* rv = a.rowvec ? a.rowvec + (size_t)(a.rowvec_map ? a.rowvec_map[n] : n) * a.rowvec_ld : nullptr;
 #pragma unroll
       for (int cf = 0; cf < 4; ++cf) {
         const int c = wave * 64 + cf * 16 + lq * 4;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f}, rw = {0.f, 0.f, 0.f, 0.f};
-        if (a.bo) b = *reinterpret_cast<const f32x4*>(a.bo + c);
-        if (rv) rw = *reinterpret_cast<const f32x4*>(rv + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(tab + 3 * C + c);
+        const f32x4 rw = *reinterpret_cast<const f32x4*>(tab + 4 * C + c);
 #pragma unroll
         for (int tf = 0; tf < 4; ++tf) {
           char* hp = img1 + (tf * 16 + lr) * PB + c * 2;
@@ -292,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
         }
       }
       tb_lds_barrier();
+      TB_STAMP(11);
     }
   });
 
@@ -304,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void tblock_front_kernel(const TbArgs a) {
       *reinterpret_cast<chunk16*>(og + (size_t)row * a.ld_out + c * 8) = *reinterpret_cast<const chunk16*>(img1 + row * PB + c * 16);
     }
   }
+  TB_STAMP(12);
 }
 
 extern "C" int32_t dc_tblock_front_ok(const dc_tblock_front_params* p) {
@@ -332,12 +362,13 @@ extern "C" int dc_tblock_front(const dc_tblock_front_params* p, dc_stream stream
   a.x = p->x; a.Wp = p->Wp; a.bp = p->bp; a.ln_g = p->ln_g; a.ln_b = p->ln_b; a.Wqkv = p->Wqkv; a.Wo = p->Wo; a.bo = p->bo;
   a.rowvec = p->rowvec; a.rowvec_map = p->rowvec_map; a.out = p->out;
   a.n = p->n; a.ldx = p->ldx; a.ld_out = p->ld_out; a.rowvec_ld = p->rowvec_ld; a.ln_eps = p->ln_eps; a.scale = p->scale;
-  constexpr int lds = 2 * 64 * (256 * 2 + 16);
+  constexpr int lds = 2 * 64 * (256 * 2 + 16) + 5 * 256 * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  void (*kern)(const TbArgs) = p->dtype == DC_BF16 ? (p->heads == 4 ? tblock_front_kernel<__bf16, 64> : tblock_front_kernel<__bf16, 32>)
-                                                   : (p->heads == 4 ? tblock_front_kernel<_Float16, 64> : tblock_front_kernel<_Float16, 32>);
-  static bool done[2][2] = {{false, false}, {false, false}};
-  bool& d = done[p->dtype == DC_BF16 ? 0 : 1][p->heads == 4 ? 0 : 1];
+  const bool bf = p->dtype == DC_BF16, h4 = p->heads == 4;
+  void (*kern)(const TbArgs) = bf ? (h4 ? tblock_front_kernel<__bf16, 64> : tblock_front_kernel<__bf16, 32>)
+                                  : (h4 ? tblock_front_kernel<_Float16, 64> : tblock_front_kernel<_Float16, 32>);
+  static bool done[2][2] = {};
+  bool& d = done[bf ? 0 : 1][h4 ? 0 : 1];
   if (!d) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); d = true; }
   hipLaunchKernelGGL(kern, dim3((unsigned)p->n), dim3(256), lds, s, a);
   return dc_check_launch("dc_tblock_front");

@@ -692,6 +692,21 @@ class UNetWeights:
             ln_gamma=sd[tb_ + ".norm3.weight"], ln_beta=sd[tb_ + ".norm3.bias"])
         return P
 
+    def fold_proj_out(self, key):
+        """proj_out folded into the feed-forward's second linear: with h3 = W2 f + b2 + h2 (ff.net.2 + residual) the block's output
+        x + Wpo h3 + bpo equals x + [Wpo W2 | Wpo] [f ; h2] + (Wpo b2 + bpo) — ONE GEMM over K = 4C + C with x as its residual instead of
+        two (h3 never exists).  Exact algebra; the product matrix is formed in fp64 and rounded once to the compute dtype.
+        Packs `<key>.ffpo.w` [C, 5C] and `<key>.ffpo.b`."""
+        P, sd = self.P, self._sd
+        if key + ".ffpo.w" not in P:
+            tb_ = key + ".transformer_blocks.0"
+            w2, b2 = sd[tb_ + ".ff.net.2.weight"].double(), sd[tb_ + ".ff.net.2.bias"].double()
+            wpo = sd[key + ".proj_out.weight"].double()
+            wpo = wpo.reshape(wpo.shape[0], -1)
+            P[key + ".ffpo.w"] = pack_matrix(torch.cat([wpo @ w2, wpo], 1).float(), self.dt, self.dev)
+            P[key + ".ffpo.b"] = f32c((sd[key + ".proj_out.bias"].double() + wpo @ b2).float(), self.dev)
+        return P
+
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.P.values())
 
@@ -721,6 +736,7 @@ class UNetPlan:
         fold_ln = os.environ.get("DCAMD_NO_LN_FOLD") is None
         # the attention half of a transformer block (proj_in ... to_out) as one launch where libdcamd serves the shape (tblock.hip)
         fuse_tb = os.environ.get("DCAMD_NO_TBLOCK") is None
+        fold_po = os.environ.get("DCAMD_NO_PO_FOLD") is None
         # GroupNorm(+SiLU) applied by the consuming 3x3 conv's loader waves (conv3_ws.hip) from the producer's quad records: no
         # GroupNorm launch, the normalised tensor never exists (DCAMD_NO_GN_WS: the GroupNorm pass + the plain conv, for A/B runs)
         fuse_ws = os.environ.get("DCAMD_NO_GN_WS") is None and use_qs
@@ -888,6 +904,10 @@ class UNetPlan:
                 hn = pb.layernorm(tbk + ".ln3", h, pb.const(P[tbk + ".norm3.g"]), pb.const(P[tbk + ".norm3.b"]), 1e-5)
                 f = pb.igemm(tbk + ".geglu", hn, pb.const(P[tbk + ".ff.net.0.proj.w"]), 8 * Cc,
                              bias=pb.const(P[tbk + ".ff.net.0.proj.b"]), act=L.ACT_GEGLU)
+            if fold_po:
+                # ff.net.2 and proj_out as one GEMM over [f | h] (UNetWeights.fold_proj_out): no ff_out tensor, one launch fewer
+                weights.fold_proj_out(key)
+                return pb.igemm(key + ".ff_proj_out", f, pb.const(P[key + ".ffpo.w"]), Cc, src1=h, bias=pb.const(P[key + ".ffpo.b"]), residual=x)
             h = pb.igemm(tbk + ".ff_out", f, pb.const(P[tbk + ".ff.net.2.w"]), Cc, bias=pb.const(P[tbk + ".ff.net.2.b"]),
                          residual=h)
             return pb.igemm(key + ".proj_out", h, pb.const(P[key + ".proj_out.w"]), Cc, bias=pb.const(P[key + ".proj_out.b"]),
