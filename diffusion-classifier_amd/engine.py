@@ -670,11 +670,16 @@ class UNetWeights:
             w = sd[key + ".conv1.weight"]
             P[key + ".conv1.wa"] = pack_conv3x3(w, self.dt, self.dev, c_lo=0, c_hi=C0)
             P[key + ".conv1.wb"] = pack_conv3x3(w, self.dt, self.dev, c_lo=C0)
-            if key + ".conv_shortcut.weight" in sd:
-                ws = sd[key + ".conv_shortcut.weight"]
-                ws = ws.reshape(ws.shape[0], -1)
-                P[key + ".conv_shortcut.wa"] = pack_matrix(ws[:, :C0], self.dt, self.dev)
-                P[key + ".conv_shortcut.wb"] = pack_matrix(ws[:, C0:], self.dt, self.dev)
+        return self.split_shortcut(key, C0)
+
+    def split_shortcut(self, key, C0):
+        """`.conv_shortcut.wa/.wb`: the 1x1 shortcut's columns for channels [0, C0) / [C0, C0+C1) of the concatenated input."""
+        P, sd = self.P, self._sd
+        if key + ".conv_shortcut.weight" in sd and key + ".conv_shortcut.wa" not in P:
+            ws = sd[key + ".conv_shortcut.weight"]
+            ws = ws.reshape(ws.shape[0], -1)
+            P[key + ".conv_shortcut.wa"] = pack_matrix(ws[:, :C0], self.dt, self.dev)
+            P[key + ".conv_shortcut.wb"] = pack_matrix(ws[:, C0:], self.dt, self.dev)
         return P
 
     def fold_layernorms(self, tb_):
@@ -850,13 +855,18 @@ class UNetPlan:
             n2g, n2b = pb.const(P[key + ".norm2.g"]), pb.const(P[key + ".norm2.b"])
             # conv_shortcut folded into conv2: the 1x1 over the raw input becomes extra K chunks of conv2's own MFMA loop
             # (conv3_halo side source) — no shortcut launch, no shortcut tensor written and read back
-            fold = (fold_short and key + ".conv_shortcut.w" in P and (x1 is None or split)
-                    and pb.side_ok(h, x0, Cout, residual=x1 if split else None))
+            # (the SHORTCUT of a class-shared skip splits even where a GroupNorm group straddles the seam and norm1 / conv1 cannot:
+            #  shortcut(cat(x0, x1)) = Wa x0 + Wb x1 is linear — the x1 half once per pair, the x0 half as conv2's side source)
+            split_sc = split or (split_skips and x1 is not None and x1.dom == "bj" and x0.dom == "unit" and key + ".conv_shortcut.w" in P)
+            fold = (fold_short and key + ".conv_shortcut.w" in P and (x1 is None or split_sc)
+                    and pb.side_ok(h, x0, Cout, residual=x1 if split_sc else None))
             if fold:
                 if key + ".conv2.bs" not in P:
                     P[key + ".conv2.bs"] = (P[key + ".conv2.b"] + P[key + ".conv_shortcut.b"]).contiguous()
-                ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout) if split else None
-                w2 = P[key + ".conv_shortcut.wa"] if split else P[key + ".conv_shortcut.w"]
+                if split_sc:
+                    weights.split_shortcut(key, x0.C)
+                ss = pb.igemm(key + ".shorts", x1, pb.const(P[key + ".conv_shortcut.wb"]), Cout) if split_sc else None
+                w2 = P[key + ".conv_shortcut.wa"] if split_sc else P[key + ".conv_shortcut.w"]
                 return gn_conv3(key + ".gn2", key + ".conv2", h_raw, n2g, n2b, G, pb.const(P[key + ".conv2.w"]), Cout,
                                 bias=pb.const(P[key + ".conv2.bs"]), residual=ss, side=(x0, pb.const(w2)), qstats=use_qs)
             if split and key + ".conv_shortcut.w" in P:
