@@ -34,6 +34,8 @@ def family(kernel):
         if "_Accum" in k:          # rocprofv3's demangler garbles <__bf16, bool>: the bench runs it in bf16 only
             dt, gn = "bf16", True
         return f"conv3_ws<{dt},gn>" if gn else f"conv3_ws<{dt}>"
+    if "tblock_front_kernel" in k:
+        return "tblock_front"
     if "igemm_wide8_kernel" in k:
         return f"igemm_wide8<{dt},256x256>"
     if "conv3_thin_kernel" in k:
