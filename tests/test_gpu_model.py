@@ -170,6 +170,38 @@ def test_class_shared_skip_halves_match_the_unsplit_plan(monkeypatch):
     assert relerr(outs[0], outs[1]) < 1e-5, relerr(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtname,tol", [("f32", 1e-5), ("bf16", 1.2e-2)])
+def test_transformer_front_launch_proj_out_fold_and_shortcut_split_match_the_chain_plan(monkeypatch, dtname, tol):
+    """Second half of round 4: (a) proj_in -> LayerNorm -> q/k/v -> attention -> to_out of a 64-token block as ONE launch (dc_tblock_front,
+    16-bit only), (b) proj_out folded into the feed-forward's second linear ([Wpo W2 | Wpo] over [f | h]), (c) the 1x1 shortcut of a
+    class-shared skip split although a GroupNorm group straddles the seam.  Same network; (b) and (c) are exact algebra (f32: summation order
+    only), (a) rounds where the chain stores."""
+    kw = dca.cifar10_unet_kwargs()
+    torch.manual_seed(28)
+    N = 2
+    x, lam, emb = torch.randn(N, 3, 32, 32), torch.tensor([3.0, -5.0]), torch.randn(N, 1, 128)
+    outs, fams, names = [], [], []
+    for on in (True, False):
+        for v in ("DCAMD_NO_TBLOCK", "DCAMD_NO_PO_FOLD", "DCAMD_NO_SKIP_SPLIT"):
+            if on:
+                monkeypatch.delenv(v, raising=False)
+            else:
+                monkeypatch.setenv(v, "1")
+        m, _ = make_pair(kw, seed=7)
+        m = m.to(DEV).set_compute_dtype(dtname)
+        outs.append(m(x.to(DEV), lam.to(DEV), encoder_hidden_states=emb.to(DEV)).float().cpu())
+        plan = next(iter(m._plans.values()))
+        fams.append([mt["family"] for mt in plan.pb.meta])
+        names.append([mt["name"] for mt in plan.pb.meta])
+    n_front = sum(f == "tblock_front" for f in fams[0])
+    # the four per-class 8x8-level blocks take the launch; the class-shared first transformer (its proj_in ... attention run per pair, to_out per class) keeps the chain
+    assert n_front == (4 if dtname != "f32" else 0) and "tblock_front" not in fams[1], (n_front, dtname)
+    assert sum(n.endswith(".ff_proj_out") for n in names[0]) == 11 and not any(n.endswith(".ff_proj_out") for n in names[1])
+    assert sum(n.endswith(".proj_out") for n in names[1]) == 11
+    print(f"{dtname}: plans with / without the three changes differ by {relerr(outs[0], outs[1]):.2e} (bound {tol:.1e}); {len(names[0])} vs {len(names[1])} launches")
+    assert relerr(outs[0], outs[1]) < tol, relerr(outs[0], outs[1])
+
+
 def test_producer_side_groupnorm_statistics_match_the_swept_plan(monkeypatch):
     """3x3 convs hand (sum, sumsq) quad statistics of their output to the GroupNorm that follows (dc_igemm qstats), which
     then streams the tensor once.  Same statistics up to fp32 summation order."""
