@@ -1568,3 +1568,34 @@ def test_tblock_front_matches_the_separate_launches(dt, n, heads):
     # shapes it does not serve are refused, not mis-computed
     bad = L.TblockFrontParams(dtype=dt, n=n, L=16, C=512, heads=8, ldx=512, ld_out=512)
     assert lib.dc_tblock_front_ok(bad) == 0
+
+
+@pytest.mark.parametrize("dt", [L.DC_BF16, L.DC_F16])
+@pytest.mark.parametrize("M,K,NH,rowln", [(96 * 5, 256, 256, True), (1000, 256, 1024, False), (96 * 3 + 7, 256, 384, True), (64 * 3 + 7, 512, 384, True), (4096, 512, 2048, True)])
+def test_geglu_projection_kernel(dt, M, K, NH, rowln):
+    """The GEGLU projection (K = 256: its own kernel igemm_xgeglu_kernel — bias, no residual; static ring slots and waits, buffer-descriptor
+    weight / bias / output accesses; K = 512: the general activation-stationary kernel) against PyTorch fp32 on the same rounded operands —
+    plain and with the row LayerNorm folded in, M ragged against the 96- / 64-row workgroups (rows past M are fetched as duplicates and their
+    stores dropped by the buffer range check / the row mask)."""
+    torch.manual_seed(M + K)
+    td = TD[dt]
+    q = lambda t: t.to(td).float()
+    x = q(torch.randn(M, K) * (2.0 if rowln else 1.0) + (0.3 if rowln else 0.0))
+    w, b = q(torch.randn(2 * NH, K) / K ** 0.5), 0.2 * torch.randn(2 * NH)
+    a = q(F.layer_norm(x, (K,), eps=1e-5)) if rowln else x
+    u, g = (a @ w.t() + b).chunk(2, dim=-1)
+    ref = u * F.gelu(g)
+    perm = E.geglu_perm(NH)
+    Wp, bp = E.pack_matrix(w[perm], dt, DEV), b[perm].contiguous().to(DEV)
+    xd = x.to(td).to(DEV)
+    guard = 4096                                       # elements behind the output that must stay untouched
+    buf = torch.full((M * NH + guard,), 7.0, dtype=td, device=DEV)
+    kw = dict(dtype=dt, taps=1, stride=1, upsample=0, n_img=1, Hin=M, Win=1, Hout=M, Wout=1, src0=ptr(xd), C0=K, ld0=K, W=ptr(Wp), Cout=2 * NH,
+              tile_n=128, bias=ptr(bp), act=L.ACT_GEGLU, out=ptr(buf), out_dtype=dt, out_ld=NH, ln_eps=1e-5 if rowln else 0.0)
+    assert "xreg" in L.lib().dc_igemm_variant(L.IgemmParams(**kw)).decode()
+    run_igemm(**kw)
+    got = buf[: M * NH].float().cpu().view(M, NH)
+    assert torch.isfinite(got).all() and bool((buf[M * NH:] == 7.0).all()), "rows past M must not be stored"
+    err = maxrel(got, ref)
+    print(f"GEGLU projection M={M} K={K} hidden={NH} dt={dt} rowln={rowln}: max err / max|ref| {err:.2e} (bound {TOL[dt]:.1e})")
+    assert err < TOL[dt], err
