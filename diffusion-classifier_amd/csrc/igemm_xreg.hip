@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
 // residual / row-vector / output-type branches, 64-bit address arithmetic, accumulator zeroing, register shuffles).  A wave issues at
 // most one instruction per 4 cycles, scalar ones included, so the N tile costs the wave ~5 k cycles of issue whatever overlaps:
 // the projection was bound by its own instruction count.  Here everything the generic path decides per tile is decided once:
-//   * K is a template parameter (K = 256 is instantiated): ring slots, fragment offsets and every counted vmcnt are constants;
+//   * K is a template parameter (256 is instantiated): ring slots, fragment offsets and every counted vmcnt are constants;
 //   * weight slices and bias through buffer descriptors — one per-lane offset register for the whole kernel, the (N tile, slice) part in
 //     the scalar offset; output rows as 16-byte buffer stores whose per-lane offset is -1 (dropped by the range check) for rows past M;
 //   * the wave drains its LDS-DMA once per N tile BEHIND the epilogue's arithmetic (the slices landed long before) and in front of its
@@ -381,10 +381,9 @@ __global__ __launch_bounds__(256, 2) void igemm_xgeglu_kernel(const IgemmArgs a)
   }
   xr_wait_vmcnt<0>();                          // (the prologue's slices too)
 
-  const uint32_t sbase = lds_addr_of(smem);
-  uint32_t woff[2];
+  const char* wbase[2];
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub) woff[sub] = sbase + lds_off(wn * 64 + lr, sub * 4 + lq);
+  for (int sub = 0; sub < 2; ++sub) wbase[sub] = smem + lds_off(wn * 64 + lr, sub * 4 + lq);
   // per-lane byte offsets: bias (packed value rows of the lane's 8 hidden channels; the gate rows are 64 bytes further) and output rows
   const int bvo = (wn * 64 + (lq >> 1) * 32 + (lq & 1) * 8) * 4;
   int ovo[TM];
@@ -418,27 +417,27 @@ __global__ __launch_bounds__(256, 2) void igemm_xgeglu_kernel(const IgemmArgs a)
         else if (e1) xr_wait_vmcnt<WL>();
         else xr_wait_vmcnt<0>();
       }
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();            // everyone's pieces of slice ks are in; everyone is done with the slot refilled next
+      asm volatile("" ::: "memory");           // (the plain LDS reads below stay behind the barrier)
       if constexpr (ks + PD < SPN) issue(nt, ks + PD);
       else if (has_next) issue(nt + 1, ks + PD - SPN);
-      constexpr int sl = (ks % R) * XR_SLICE;   // (< 64 KiB with the fragment's 2 KiB steps: the reads' immediate offset)
+      constexpr int sl = (ks % R) * XR_SLICE;
+      // fragment reads as PLAIN loads: hipcc places counted lgkmcnt waits in front of the MFMAs that use them (the asynchronous-asm reads of the
+      // kernel above need the register allocator never to copy a fragment register between its read and its wait; one variant of this kernel —
+      // fragments kept alive past their MFMAs — failed its op test with them).  With two waves per SIMD the partner's MFMAs cover the waits.
       chunk16 wf[2][TN];
-      lgkm_fence0();
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        wf[sub][0] = ds_read16_async_off<sl>(woff[sub]);
-        wf[sub][1] = ds_read16_async_off<sl + 2048>(woff[sub]);
-        wf[sub][2] = ds_read16_async_off<sl + 4096>(woff[sub]);
-        wf[sub][3] = ds_read16_async_off<sl + 6144>(woff[sub]);
-      }
-#define XG_MMA(SUB, I, NLEFT)                                                                        \
-      lgkm_wait<NLEFT>(wf[SUB][I]);                                                                  \
-      _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                 \
-        acc[I][j] = Mma<T>::run(wf[SUB][I], xr[j][2 * ks + SUB], acc[I][j]);                        \
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[sub][i] = *reinterpret_cast<const chunk16*>(wbase[sub] + sl + i * 2048);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[sub][i], xr[j][2 * ks + sub], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
-      XG_MMA(0, 0, 7) XG_MMA(0, 1, 6) XG_MMA(0, 2, 5) XG_MMA(0, 3, 4)
-      XG_MMA(1, 0, 3) XG_MMA(1, 1, 2) XG_MMA(1, 2, 1) XG_MMA(1, 3, 0)
-#undef XG_MMA
     });
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue: out = (value + bias_v) * gelu(gate + bias_g), 8 consecutive hidden channels per lane and pixel row ----
@@ -475,7 +474,7 @@ static bool xgeglu_applicable(const IgemmArgs& a) {
   static const bool off = getenv("DCAMD_NO_XGEGLU") != nullptr;
   if (off || a.act != DC_ACT_GEGLU || !a.bias) return false;
   if (a.src1 || a.map0 || a.residual || a.rowvec || a.gate) return false;
-  if (a.Ktot != 256) return false;       // (the K = 512 instance — 64-row workgroups, 8 slices per N tile — computed garbage in its first pixel fragment: not shipped)
+  if (a.Ktot != 256) return false;       // (the K = 512 instance — 64-row workgroups, 8 slices per N tile — fails the op test in its first pixel fragment: not instantiated)
   if (a.C0 != a.Ktot || a.out_ld % 8 || a.ld0 % 8 || (a.Cout & 127)) return false;
   if ((long long)a.M * a.out_ld * 2 >= (1LL << 31) || (long long)a.Cout * a.Ktot * 2 >= (1LL << 31)) return false;   // 32-bit buffer offsets
   return true;
