@@ -85,7 +85,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(dca._lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dc_abi_version() == dca._lib.ABI_VERSION == 3
+    assert lib.dc_abi_version() == dca._lib.ABI_VERSION == 4
     lib.dc_arch.restype = ctypes.c_char_p
     assert lib.dc_arch() == b"gfx950"
 
