@@ -17,7 +17,6 @@
 // so the wave drains its own DMA (vmcnt 0) BEFORE an epilogue and remembers how many slices are known to have
 // landed — the next PD slices need no wait, and by the time one is needed the stores are three slices old.
 #include <stdlib.h>
-#include <utility>
 #include "igemm_epilogue.h"
 DC_CLOCK_DECL(igemm_xreg)
 #ifdef DC_XR_STAMPS
@@ -271,227 +270,6 @@ __global__ __launch_bounds__(256, 2) void igemm_xreg_kernel(const IgemmArgs a) {
   DC_CLOCK(1);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The GEGLU projection's own kernel (round 4, second half).  Stamps of the kernel above on the cfg2 8x8-level projection
-// (tools/stamp_xreg.py): per 64-hidden-channel N tile and wave 4.05 k cycles of K loop and 3.66 k of epilogue for 1.54 k cycles
-// of MFMA issue, with only 0.5 k of them waiting for weight slices or at the barrier — and ~1280 instructions per N tile in the
-// ISA: 96 MFMAs, 456 VALU of bias + erf-GELU + product, and ~240 VALU + ~420 SALU of generic-epilogue bookkeeping (row validity,
-// residual / row-vector / output-type branches, 64-bit address arithmetic, accumulator zeroing, register shuffles).  A wave issues at
-// most one instruction per 4 cycles, scalar ones included, so the N tile costs the wave ~5 k cycles of issue whatever overlaps:
-// the projection was bound by its own instruction count.  Here everything the generic path decides per tile is decided once:
-//   * K is a template parameter (256 is instantiated): ring slots, fragment offsets and every counted vmcnt are constants;
-//   * weight slices and bias through buffer descriptors — one per-lane offset register for the whole kernel, the (N tile, slice) part in
-//     the scalar offset; output rows as 16-byte buffer stores whose per-lane offset is -1 (dropped by the range check) for rows past M;
-//   * the wave drains its LDS-DMA once per N tile BEHIND the epilogue's arithmetic (the slices landed long before) and in front of its
-//     stores, so the next tile's first PD slices need no wait and no load ever queues behind a store (vmcnt is one in-order counter).
-// Same arithmetic in the same order as epi_direct_act<GEGLU> + gelu_erf_t: the cfg2 parity figures are identical to the digit with either
-// kernel.  Measured: 0.87 -> 0.74 ms per 8x8-level projection (M = 512000, N = 2048), -0.65 ms per cfg2 step — less than the instruction
-// count promised (734 against ~1280 per N tile): the rest of the N tile is the two waves of a SIMD sharing its issue port and matrix pipe.
-template <typename F, int... I> __device__ __forceinline__ void xg_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void xg_static_for(F&& f) { xg_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-template <typename T, int TM, int KC>
-__global__ __launch_bounds__(256, 2) void igemm_xgeglu_kernel(const IgemmArgs a) {
-  static_assert(sizeof(T) == 2, "16-bit operands only");
-  constexpr int TN = XR_TN, R = XR_R, PD = XR_PD, WL = XR_WL, SPN = KC / 2, K = KC * 32;
-  static_assert(SPN % R == 0 && PD == 3 && R == 4, "an N tile's slices start at ring slot 0");
-  constexpr int WROWS = TM * 16, BM = 2 * WROWS;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int tile_m = blockIdx.x;
-  const int tiles_n = a.tiles_n;
-  auto rsrc_of = [](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
-  const __amdgpu_buffer_rsrc_t wrs = rsrc_of(a.W), brs = rsrc_of(a.bias), ors = rsrc_of(a.out);
-
-  // ---- weight loader: lane t fetches chunk (t & 7) ^ ((t >> 4) & 7) of LDS rows (t >> 3) + 32 i (the W stage image of igemm_pipe.hip) ----
-  int wvo[WL];
-  {
-    const int lrow = t >> 3, lchunk = (t & 7) ^ ((t >> 4) & 7);
-#pragma unroll
-    for (int i = 0; i < WL; ++i) wvo[i] = (epi_wrow(lrow + 32 * i, true) * K + lchunk * 8) * 2;
-  }
-  auto issue = [&](int nt, int ks) {           // slice ks of N tile nt -> ring slot ks % R (SPN % R == 0)
-    const int so = __builtin_amdgcn_readfirstlane((nt * 128 * K + ks * 64) * 2);
-    char* dst = smem + (ks % R) * XR_SLICE + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < WL; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(dst + i * 4096), 16, wvo[i], so, 0, 0);
-  };
-#pragma unroll
-  for (int p = 0; p < PD; ++p) issue(0, p);
-
-  // ---- the activation rows of this wave, once, as B-operand fragments (rows past M: duplicates of the last row, never stored) ----
-  chunk16 xr[TM][KC];
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = tile_m * BM + wm * WROWS + j * 16 + lr;
-    const T* b0 = reinterpret_cast<const T*>(a.src0) + (size_t)(m < a.M ? m : a.M - 1) * a.ld0 + lq * 8;
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) xr[j][kc] = *reinterpret_cast<const chunk16*>(b0 + kc * 32);
-  }
-#pragma unroll
-  for (int j = 0; j < TM; ++j)
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(xr[j][kc]));
-  if (a.ln_eps > 0.f) {                        // row LayerNorm without affine: the arithmetic of igemm_xreg_kernel, statement for statement
-    const float invK = 1.0f / (float)K;
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      float sum = 0.f;
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        float f[8];
-        chunk_to_f<T>(xr[j][kc], f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sum += f[e];
-      }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * invK;
-      // (opaque copies between the passes: hipcc otherwise keeps the 8 x KC converted floats of pass one alive for passes two and
-      //  three — 256 registers at K = 512 — and spills them)
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+v"(xr[j][kc]));
-      float var = 0.f;
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        float f[8];
-        chunk_to_f<T>(xr[j][kc], f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) var += (f[e] - mean) * (f[e] - mean);
-      }
-      var += __shfl_xor(var, 16, 64);
-      var += __shfl_xor(var, 32, 64);
-      const float rstd = rsqrtf(var * invK + a.ln_eps);
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+v"(xr[j][kc]));
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        float f[8];
-        chunk_to_f<T>(xr[j][kc], f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd;
-        xr[j][kc] = f_to_chunk<T>(f);
-      }
-    }
-  }
-  xr_wait_vmcnt<0>();                          // (the prologue's slices too)
-
-  const char* wbase[2];
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) wbase[sub] = smem + lds_off(wn * 64 + lr, sub * 4 + lq);
-  // per-lane byte offsets: bias (packed value rows of the lane's 8 hidden channels; the gate rows are 64 bytes further) and output rows
-  const int bvo = (wn * 64 + (lq >> 1) * 32 + (lq & 1) * 8) * 4;
-  int ovo[TM];
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = tile_m * BM + wm * WROWS + j * 16 + lr;
-    ovo[j] = m < a.M ? (m * a.out_ld + wn * 32 + lq * 8) * 2 : -1;
-  }
-
-  DC_CLOCK(0);
-  for (int nt = 0; nt < tiles_n; ++nt) {
-    const bool has_next = nt + 1 < tiles_n;
-    const int bso = __builtin_amdgcn_readfirstlane(nt * 512);
-    chunk16 braw[4];                           // value bias 0-3 / 4-7, gate bias 0-3 / 4-7: fetched ahead of the K loop
-    braw[0] = __builtin_amdgcn_raw_buffer_load_b128(brs, bvo, bso, 0);
-    braw[1] = __builtin_amdgcn_raw_buffer_load_b128(brs, bvo + 16, bso, 0);
-    braw[2] = __builtin_amdgcn_raw_buffer_load_b128(brs, bvo + 64, bso, 0);
-    braw[3] = __builtin_amdgcn_raw_buffer_load_b128(brs, bvo + 80, bso, 0);
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    xg_static_for<SPN>([&](auto ksc) {
-      constexpr int ks = decltype(ksc)::value;
-      // slices 0 .. PD-1 of a tile were drained by the previous epilogue (tile 0: by the wait above); slice ks >= PD was issued at step
-      // ks - PD and up to two younger slices may stay in flight behind it
-      if constexpr (ks >= PD) {
-        const bool e1 = ks + 1 < SPN || has_next, e2 = ks + 2 < SPN || has_next;
-        if (e1 && e2) xr_wait_vmcnt<2 * WL>();
-        else if (e1) xr_wait_vmcnt<WL>();
-        else xr_wait_vmcnt<0>();
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();            // everyone's pieces of slice ks are in; everyone is done with the slot refilled next
-      asm volatile("" ::: "memory");           // (the plain LDS reads below stay behind the barrier)
-      if constexpr (ks + PD < SPN) issue(nt, ks + PD);
-      else if (has_next) issue(nt + 1, ks + PD - SPN);
-      constexpr int sl = (ks % R) * XR_SLICE;
-      // fragment reads as PLAIN loads: hipcc places counted lgkmcnt waits in front of the MFMAs that use them (the asynchronous-asm reads of the
-      // kernel above need the register allocator never to copy a fragment register between its read and its wait; one variant of this kernel —
-      // fragments kept alive past their MFMAs — failed its op test with them).  With two waves per SIMD the partner's MFMAs cover the waits.
-      chunk16 wf[2][TN];
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[sub][i] = *reinterpret_cast<const chunk16*>(wbase[sub] + sl + i * 2048);
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[sub][i], xr[j][2 * ks + sub], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- epilogue: out = (value + bias_v) * gelu(gate + bias_g), 8 consecutive hidden channels per lane and pixel row ----
-    float bv[8], bg[8];
-    {
-      const f32x4 b0 = __builtin_bit_cast(f32x4, braw[0]), b1 = __builtin_bit_cast(f32x4, braw[1]);
-      const f32x4 g0 = __builtin_bit_cast(f32x4, braw[2]), g1 = __builtin_bit_cast(f32x4, braw[3]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; bg[e] = g0[e]; bg[4 + e] = g1[e]; }
-    }
-#pragma unroll
-    for (int j = 0; j < TM; ++j)               // in place: the value fragments 0 / 2 receive the product, the gate fragments are dead afterwards
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = acc[(e >> 2) * 2][j][e & 3] + bv[e], g = acc[(e >> 2) * 2 + 1][j][e & 3] + bg[e];
-        acc[(e >> 2) * 2][j][e & 3] = v * gelu_erf_t<T>(g);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    xr_wait_vmcnt<0>();                        // my pieces of the next PD slices (long landed): nothing of mine is in flight when the stores go out
-    const int oso = __builtin_amdgcn_readfirstlane(nt * 128);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = acc[(e >> 2) * 2][j][e & 3];
-      __builtin_amdgcn_raw_buffer_store_b128(f_to_chunk<T>(o), ors, ovo[j], oso, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  DC_CLOCK(1);
-}
-
-static bool xgeglu_applicable(const IgemmArgs& a) {
-  static const bool off = getenv("DCAMD_NO_XGEGLU") != nullptr;
-  if (off || a.act != DC_ACT_GEGLU || !a.bias) return false;
-  if (a.src1 || a.map0 || a.residual || a.rowvec || a.gate) return false;
-  if (a.Ktot != 256) return false;       // (the K = 512 instance — 64-row workgroups, 8 slices per N tile — fails the op test in its first pixel fragment: not instantiated)
-  if (a.C0 != a.Ktot || a.out_ld % 8 || a.ld0 % 8 || (a.Cout & 127)) return false;
-  if ((long long)a.M * a.out_ld * 2 >= (1LL << 31) || (long long)a.Cout * a.Ktot * 2 >= (1LL << 31)) return false;   // 32-bit buffer offsets
-  return true;
-}
-
-template <typename T, int TM, int KC>
-static int xgeglu_launch_t(const IgemmArgs& a0, hipStream_t s) {
-  constexpr int lds = XR_R * XR_SLICE;
-  IgemmArgs a = a0;
-  a.tiles_m = (a.M + 2 * TM * 16 - 1) / (2 * TM * 16);
-  static bool attr_done = false;
-  void (*kern)(const IgemmArgs) = igemm_xgeglu_kernel<T, TM, KC>;
-  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_m), dim3(256), lds, s, a);
-  return dc_check_launch("dc_igemm(xgeglu)");
-}
-
 bool dc_igemm_xreg_applicable(const IgemmArgs& a, int dtype) {
   static const bool off = getenv("DCAMD_NO_XREG") != nullptr;
   if (off || dtype == DC_F32 || a.taps != 1 || a.gate) return false;
@@ -524,8 +302,6 @@ static int xreg_launch_t(const IgemmArgs& a0, hipStream_t s) {
 int dc_igemm_xreg_launch(const IgemmArgs& a, int dtype, hipStream_t s) {
   // K <= 256: 96 rows per workgroup (3 fragments x 8 chunks = 96 activation registers per wave);
   // K <= 512: 64 rows (2 x 16 = 128 registers)
-  if (xgeglu_applicable(a) && a.out_dtype == dtype)
-    return dtype == DC_BF16 ? xgeglu_launch_t<__bf16, 3, 8>(a, s) : xgeglu_launch_t<_Float16, 3, 8>(a, s);
   if (a.Ktot <= 256) return dtype == DC_BF16 ? xreg_launch_t<__bf16, 3, 8>(a, s) : xreg_launch_t<_Float16, 3, 8>(a, s);
   return dtype == DC_BF16 ? xreg_launch_t<__bf16, 2, 16>(a, s) : xreg_launch_t<_Float16, 2, 16>(a, s);
 }

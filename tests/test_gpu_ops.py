@@ -1573,10 +1573,11 @@ def test_tblock_front_matches_the_separate_launches(dt, n, heads):
 @pytest.mark.parametrize("dt", [L.DC_BF16, L.DC_F16])
 @pytest.mark.parametrize("M,K,NH,rowln", [(96 * 5, 256, 256, True), (1000, 256, 1024, False), (96 * 3 + 7, 256, 384, True), (64 * 3 + 7, 512, 384, True), (4096, 512, 2048, True)])
 def test_geglu_projection_kernel(dt, M, K, NH, rowln):
-    """The GEGLU projection (K = 256: its own kernel igemm_xgeglu_kernel — bias, no residual; static ring slots and waits, buffer-descriptor
-    weight / bias / output accesses; K = 512: the general activation-stationary kernel) against PyTorch fp32 on the same rounded operands —
-    plain and with the row LayerNorm folded in, M ragged against the 96- / 64-row workgroups (rows past M are fetched as duplicates and their
-    stores dropped by the buffer range check / the row mask)."""
+    """The GEGLU projection of the UNet transformer blocks (activation-stationary kernel, K = 256 / 512) against PyTorch fp32 on the same rounded
+    operands — plain and with the row LayerNorm folded in, M ragged against the 96- / 64-row workgroups (rows past M are fetched as duplicates
+    and never stored: the elements behind the output stay untouched) — and launched twice: the two results must be bit-identical (a trimmed
+    variant of this kernel, round 4, computed the right values within tolerance and different ones on every launch once two workgroups shared
+    a CU; only the model-level repeat test caught it)."""
     torch.manual_seed(M + K)
     td = TD[dt]
     q = lambda t: t.to(td).float()
@@ -1599,3 +1600,43 @@ def test_geglu_projection_kernel(dt, M, K, NH, rowln):
     err = maxrel(got, ref)
     print(f"GEGLU projection M={M} K={K} hidden={NH} dt={dt} rowln={rowln}: max err / max|ref| {err:.2e} (bound {TOL[dt]:.1e})")
     assert err < TOL[dt], err
+    first = buf.clone()
+    run_igemm(**kw)
+    assert torch.equal(first.view(torch.int16), buf.view(torch.int16)), "a repeated launch must give the same bits"
+
+
+@pytest.mark.parametrize("which", ["geglu_k256", "geglu_k512", "tblock_front"])
+def test_transformer_kernels_are_deterministic_at_bench_size(which):
+    """Launch-to-launch bit-identity at the size the bench runs (8000 samples x 64 tokens: more workgroups than the chip holds at once, two per
+    CU), other traffic in between: dc_tblock_front and the GEGLU projections."""
+    torch.manual_seed(77)
+    lib, dt, td = L.lib(), L.DC_BF16, torch.bfloat16
+    outs = []
+    if which == "tblock_front":
+        n, Lq, Cc, heads = 8000, 64, 256, 8
+        x = torch.randn(n, Lq, Cc, device=DEV).to(td)
+        Wp, Wq, Wo = (E.pack_matrix(torch.randn(r, Cc) / Cc ** 0.5, dt, DEV) for r in (Cc, 3 * Cc, Cc))
+        bp, bo, g, b = (torch.randn(Cc, device=DEV) * 0.1 for _ in range(4))
+        cv = torch.randn(10, Cc, device=DEV)
+        cm = (torch.arange(n, device=DEV, dtype=torch.int32) % 10).contiguous()
+        for _ in range(3):
+            out = torch.empty(n, Lq, Cc, dtype=td, device=DEV)
+            tp = L.TblockFrontParams(x=ptr(x), Wp=ptr(Wp), bp=ptr(bp), ln_g=ptr(g), ln_b=ptr(b), Wqkv=ptr(Wq), Wo=ptr(Wo), bo=ptr(bo), rowvec=ptr(cv),
+                                     rowvec_map=ptr(cm), out=ptr(out), dtype=dt, n=n, L=Lq, C=Cc, heads=heads, ldx=Cc, ld_out=Cc, rowvec_ld=Cc,
+                                     ln_eps=1e-5, scale=(Cc // heads) ** -0.5)
+            torch.randn(1 << 22, device=DEV).sum()
+            L.check(lib.dc_tblock_front(tp, L.stream_ptr()), "dc_tblock_front")
+            outs.append(out)
+    else:
+        M, K, NH = (512000, 256, 1024) if which == "geglu_k256" else (128000, 512, 2048)
+        x = (torch.randn(M, K, device=DEV) * 1.5 + 0.2).to(td)
+        Wp, bp = E.pack_geglu(torch.randn(2 * NH, K) / K ** 0.5, torch.randn(2 * NH) * 0.1, dt, DEV, ln_gamma=torch.ones(K), ln_beta=torch.zeros(K))
+        for _ in range(3):
+            out = torch.empty(M, NH, dtype=td, device=DEV)
+            torch.randn(1 << 22, device=DEV).sum()
+            run_igemm(dtype=dt, taps=1, stride=1, upsample=0, n_img=1, Hin=M, Win=1, Hout=M, Wout=1, src0=ptr(x), C0=K, ld0=K, W=ptr(Wp), Cout=2 * NH,
+                      tile_n=128, bias=ptr(bp), act=L.ACT_GEGLU, out=ptr(out), out_dtype=dt, out_ld=NH, ln_eps=1e-5)
+            outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16)), f"{which}: a repeated launch differs in {(o.view(torch.int16) != outs[0].view(torch.int16)).sum().item()} elements"

@@ -47,7 +47,7 @@ def family(kernel):
         if len(ints) > 3 and ints[3] == 5:                      # EV = 5: four-phase upsample conv on the tap-gather kernel
             return f"igemm_pipe_up4<{dt},{bm}x{128 * nh},{st}st>"
         return f"igemm_pipe<{dt},{bm}x{128 * nh},{st}st>"
-    if "igemm_xreg_kernel" in k or "igemm_xgeglu_kernel" in k:       # (the GEGLU projection's own kernel reports under the same family)
+    if "igemm_xreg_kernel" in k:
         return "igemm_xreg<bf16,96xN>" if dt == "f32" else f"igemm_xreg<{dt},96xN>"   # demangler drops the type: 16-bit only kernel
     if "igemm_kernel" in k:
         return f"igemm<{dt},{ints[0]}x{ints[1]}>"
