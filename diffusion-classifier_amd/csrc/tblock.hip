@@ -3,7 +3,7 @@
 //
 //   h   = proj_in(x) + b                       x: the GroupNorm'd block input [n][64][C]
 //   hn  = LayerNorm(h) * gamma + beta
-//   q, k, v = hn Wq^T, hn Wk^T, hn Wv^T        (no bias), heads of 64 channels
+//   q, k, v = hn Wq^T, hn Wk^T, hn Wv^T        (no bias), heads of 32 or 64 channels
 //   o   = softmax(q k^T * scale) v             per (sample, head)
 //   out = (to_out(o) + b_o) + rowvec[sample] + h        rowvec: the cross-attention's per-class vector (one context token)
 //
@@ -11,8 +11,9 @@
 // 2-4 TB/s (1.1 ms per block and cfg2 step for 0.4 TFLOP).  Here one 4-wave workgroup owns one sample:
 //   * two LDS images [64 tokens][C] (row pitch + 16 B: the 16 rows of a fragment read cover the 64 banks once) hold x -> hn -> o and
 //     h -> out; a sample enters and leaves HBM once, as whole rows;
-//   * wave w owns output channels 64 w .. + 63 of EVERY GEMM (one head of 64 channels or two of 32): its weight rows come straight from L2 into registers as
-//     MFMA A-operand fragments (16 B per lane, two k-steps ahead), never through LDS — no other wave of the workgroup wants them;
+//   * wave w owns output channels 64 w .. + 63 of EVERY GEMM (one head of 64 channels or two of 32): its weight rows come straight from
+//     L2 into registers as MFMA A-operand fragments (16 B per lane, two k-steps ahead), never through LDS — no other wave of the
+//     workgroup wants them;
 //   * every GEMM is D[cout][token] = W[cout][:] . X[token][:] (16x16x32 MFMA, A = W rows, B = X rows from the LDS image), so a lane
 //     ends up with 4 consecutive channels of one token.  Packed in pairs of channel fragments those ARE the operands of the score
 //     product (the k order inside an MFMA is free as long as A and B agree): S^T = K Q^T needs no LDS round trip.  V is computed with
